@@ -1,0 +1,59 @@
+"""Builds libdfine_hip.so (every csrc/*.hip, gfx950 only) in-tree with hipcc.
+
+The .so is git-ignored but travels to the GPU box with the gpurun snapshot; hipcc
+cross-compiles without a GPU, so `build()` is also the CPU-side "does it build" check.
+"""
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(PKG_DIR, "csrc")
+INCLUDE_DIR = os.path.join(os.path.dirname(PKG_DIR), "include")
+LIB_PATH = os.path.join(CSRC_DIR, "libdfine_hip.so")
+
+HIPCC_FLAGS = [
+    "-O3",
+    "-std=c++17",
+    "--offload-arch=gfx950",
+    "-munsafe-fp-atomics",  # hardware global_atomic_add_f32, never a CAS loop
+    "-fPIC",
+    "-shared",
+]
+
+
+def sources():
+    return sorted(
+        os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith(".hip")
+    )
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    deps = sources() + [
+        os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith(".h")
+    ]
+    deps += [os.path.join(INCLUDE_DIR, f) for f in os.listdir(INCLUDE_DIR)]
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
+def find_hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libdfine_hip.so cannot be built")
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip into libdfine_hip.so if it is missing or older than its sources."""
+    if not force and not _stale():
+        return LIB_PATH
+    cmd = [find_hipcc(), *HIPCC_FLAGS, f"-I{INCLUDE_DIR}", f"-I{CSRC_DIR}", "-o", LIB_PATH, *sources()]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+    return LIB_PATH

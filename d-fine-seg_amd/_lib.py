@@ -1,0 +1,94 @@
+"""ctypes binding of libdfine_hip.so (the C ABI declared in include/dfine_hip.h).
+
+There is no fallback: if the library is missing, or a tensor is not on the GPU, the call
+raises. Nothing here imports the CPU oracle.
+"""
+import ctypes
+import os
+
+import torch  # imported first so the HIP runtime torch ships is the one the .so binds to
+
+from ._build import LIB_PATH
+
+_c_void_p, _c_int = ctypes.c_void_p, ctypes.c_int
+_i32p = ctypes.POINTER(ctypes.c_int32)
+
+# name -> argtypes; must list EVERY symbol include/dfine_hip.h declares (tests check this)
+SIGNATURES = {
+    "dfine_abi_version": [],
+    "dfine_msda_fwd": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]
+    + [_c_int] * 6
+    + [_i32p, _i32p, _c_void_p],
+    "dfine_msda_bwd": [_c_void_p, _c_int] + [_c_void_p] * 6 + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class DfineHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdfine_hip.so once; raise loudly if it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DfineHipError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc, gfx950). The HIP path has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _c_int
+    got = lib.dfine_abi_version()
+    if got != ABI_VERSION:
+        raise DfineHipError(f"libdfine_hip.so ABI {got} != expected {ABI_VERSION}: rebuild it")
+    _lib = lib
+    return lib
+
+
+_ERRORS = {-1: "bad argument", -2: "unsupported shape/dtype"}
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = _ERRORS.get(rc, f"hipError_t {rc}")
+        raise DfineHipError(f"{what} failed: {msg}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DfineHipError(
+                "HIP op called with a CPU tensor: the product path runs on MI355X only "
+                "(the CPU restatement lives in oracle/ and is test infrastructure)"
+            )
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def i32_array(values):
+    flat = [int(v) for v in values]
+    return (ctypes.c_int32 * len(flat))(*flat)
+
+
+DT_F32, DT_BF16 = 0, 1
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return DT_F32
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    raise DfineHipError(f"unsupported dtype {t.dtype} (float32 or bfloat16 only)")

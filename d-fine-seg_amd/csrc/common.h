@@ -1,0 +1,82 @@
+// Shared device helpers for libdfine_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dfine_hip.h"
+
+#define DFINE_LAUNCH_CHECK()                       \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+
+namespace dfine {
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+
+// Round-to-nearest-even f32 -> bf16. A plain cast lowers to v_cvt_pk_bf16_f32 on gfx950,
+// which keeps NaN a NaN (the integer-add trick does not).
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+
+// 16-byte vector of T, as 4 dwords, for coalesced 16 B/lane global accesses.
+struct alignas(16) Vec16 {
+  uint32_t w[4];
+};
+
+template <typename T>
+struct VecTraits;
+
+template <>
+struct VecTraits<float> {
+  static constexpr int kElems = 4;
+  __device__ static __forceinline__ void unpack(const Vec16& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v.w[i]);
+  }
+  __device__ static __forceinline__ Vec16 pack(const float* f) {
+    Vec16 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v.w[i] = __float_as_uint(f[i]);
+    return v;
+  }
+  __device__ static __forceinline__ float load1(const float* p) { return *p; }
+};
+
+template <>
+struct VecTraits<bf16_t> {
+  static constexpr int kElems = 8;
+  __device__ static __forceinline__ void unpack(const Vec16& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(v.w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(v.w[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ Vec16 pack(const float* f) {
+    Vec16 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      v.w[i] = (uint32_t)f32_to_bf16(f[2 * i]) | ((uint32_t)f32_to_bf16(f[2 * i + 1]) << 16);
+    return v;
+  }
+  __device__ static __forceinline__ float load1(const bf16_t* p) { return bf16_to_f32(*p); }
+};
+
+// Sum over aligned groups of WIDTH lanes (WIDTH a power of two <= 64); every lane of the
+// group ends with the group's sum.
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int m = WIDTH / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+}  // namespace dfine

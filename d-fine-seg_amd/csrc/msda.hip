@@ -1,0 +1,284 @@
+// Multi-scale deformable attention core for gfx950: the bilinear gather behind the D-FINE
+// decoder's cross-attention. Semantics follow deformable_attention_core_func_v2
+// (reference src/d_fine/arch/utils.py:191-264: grid = 2*loc-1, F.grid_sample bilinear /
+// zeros / align_corners=False  =>  pixel = loc*size - 0.5, out-of-image corners read 0),
+// re-laid-out channel-last so one corner of one head is one contiguous segment.
+//
+// Both kernels are HBM/L2-gather bound (no contraction worth an MFMA): the forward moves
+// Lq*nH*P*4 corner segments of c elements per image, the backward the same reads plus the
+// same number of float-atomic segments into grad_value.
+#include "common.h"
+
+namespace dfine {
+
+struct MsdaGeom {
+  int n_levels;
+  int P;                        // points per head, all levels
+  int H[DFINE_MAX_LEVELS];
+  int W[DFINE_MAX_LEVELS];
+  int start[DFINE_MAX_LEVELS];  // first row of level l inside S
+  int pt_begin[DFINE_MAX_LEVELS + 1];  // level l owns points [pt_begin[l], pt_begin[l+1])
+};
+
+// One sampling point -> 4 clamped row indices + 4 bilinear weights (0 for corners outside
+// the map, so loads can stay unconditional and in-bounds).
+struct Corners {
+  int r00, r01, r10, r11;  // row = start + y*W + x
+  float w00, w01, w10, w11;
+  float fx, fy;
+  bool vx0, vx1, vy0, vy1;
+};
+
+__device__ __forceinline__ Corners make_corners(float lx, float ly, int H, int W, int start) {
+  Corners k;
+  const float x = lx * (float)W - 0.5f;
+  const float y = ly * (float)H - 0.5f;
+  // Anything not strictly inside (-1, size) touches no pixel (also catches NaN/Inf).
+  const bool live = (x > -1.0f) && (x < (float)W) && (y > -1.0f) && (y < (float)H);
+  const float xs = live ? x : 0.0f, ys = live ? y : 0.0f;
+  const float xf = floorf(xs), yf = floorf(ys);
+  const int x0 = (int)xf, y0 = (int)yf;
+  k.fx = xs - xf;
+  k.fy = ys - yf;
+  k.vx0 = live && x0 >= 0;
+  k.vx1 = live && (x0 + 1) < W;
+  k.vy0 = live && y0 >= 0;
+  k.vy1 = live && (y0 + 1) < H;
+  const int xc0 = max(x0, 0), xc1 = min(x0 + 1, W - 1);
+  const int yc0 = max(y0, 0), yc1 = min(y0 + 1, H - 1);
+  k.r00 = start + yc0 * W + xc0;
+  k.r01 = start + yc0 * W + xc1;
+  k.r10 = start + yc1 * W + xc0;
+  k.r11 = start + yc1 * W + xc1;
+  k.w00 = (k.vx0 && k.vy0) ? (1.0f - k.fx) * (1.0f - k.fy) : 0.0f;
+  k.w01 = (k.vx1 && k.vy0) ? k.fx * (1.0f - k.fy) : 0.0f;
+  k.w10 = (k.vx0 && k.vy1) ? (1.0f - k.fx) * k.fy : 0.0f;
+  k.w11 = (k.vx1 && k.vy1) ? k.fx * k.fy : 0.0f;
+  return k;
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward. A "pair" is one (batch, query, head). C/VEC lanes share a pair, each owning a
+// 16-byte slice of the head's channels, so every corner is read as one 16 B/lane access and
+// a pair's corner is one contiguous C*sizeof(T) segment (64 B for bf16, c=32).
+// ------------------------------------------------------------------------------------------
+template <typename T, int C>
+__global__ __launch_bounds__(256) void msda_fwd_kernel(const T* __restrict__ value,
+                                                        const float* __restrict__ loc,
+                                                        const float* __restrict__ attn,
+                                                        T* __restrict__ out, MsdaGeom g,
+                                                        int n_pairs, int S, int Lq, int nH) {
+  constexpr int VEC = VecTraits<T>::kElems;
+  constexpr int LPP = C / VEC;  // lanes per pair
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pair = tid / LPP;
+  if (pair >= n_pairs) return;
+  const int sub = tid % LPP;
+  const int h = pair % nH;
+  const int b = pair / (nH * Lq);
+  const int row_stride = nH * C;  // elements between consecutive rows of S
+  const T* vbase = value + ((size_t)b * S * nH + h) * C + sub * VEC;
+  const float* lp = loc + (size_t)pair * g.P * 2;
+  const float* ap = attn + (size_t)pair * g.P;
+
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.0f;
+
+  for (int l = 0; l < g.n_levels; ++l) {
+    const int H = g.H[l], W = g.W[l], start = g.start[l];
+#pragma unroll 3
+    for (int p = g.pt_begin[l]; p < g.pt_begin[l + 1]; ++p) {
+      const float2 xy = *reinterpret_cast<const float2*>(lp + 2 * p);
+      const float a = ap[p];
+      const Corners k = make_corners(xy.x, xy.y, H, W, start);
+      const Vec16 q00 = *reinterpret_cast<const Vec16*>(vbase + (size_t)k.r00 * row_stride);
+      const Vec16 q01 = *reinterpret_cast<const Vec16*>(vbase + (size_t)k.r01 * row_stride);
+      const Vec16 q10 = *reinterpret_cast<const Vec16*>(vbase + (size_t)k.r10 * row_stride);
+      const Vec16 q11 = *reinterpret_cast<const Vec16*>(vbase + (size_t)k.r11 * row_stride);
+      float v00[VEC], v01[VEC], v10[VEC], v11[VEC];
+      VecTraits<T>::unpack(q00, v00);
+      VecTraits<T>::unpack(q01, v01);
+      VecTraits<T>::unpack(q10, v10);
+      VecTraits<T>::unpack(q11, v11);
+      const float c00 = a * k.w00, c01 = a * k.w01, c10 = a * k.w10, c11 = a * k.w11;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i)
+        acc[i] += c00 * v00[i] + c01 * v01[i] + c10 * v10[i] + c11 * v11[i];
+    }
+  }
+  *reinterpret_cast<Vec16*>(out + (size_t)pair * C + sub * VEC) = VecTraits<T>::pack(acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward. One lane per channel, C lanes per pair, so every float-atomic wave instruction
+// is 64/C contiguous segments of C*4 bytes (two 128-B segments at c=32: the full-rate shape
+// for global_atomic_add_f32 on gfx950). grad_attn / grad_loc need a sum over the pair's
+// channels: a shuffle tree over C lanes, written by the pair's first lane.
+// ------------------------------------------------------------------------------------------
+template <typename T, int C>
+__global__ __launch_bounds__(256) void msda_bwd_kernel(
+    const T* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
+    const T* __restrict__ grad_out, float* __restrict__ grad_value, float* __restrict__ grad_loc,
+    float* __restrict__ grad_attn, MsdaGeom g, int n_pairs, int S, int Lq, int nH) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pair = tid / C;
+  // n_pairs*C is padded to the block size by the host, so whole C-lane groups are either
+  // all live or all dead; dead groups still take part in the shuffles below.
+  const bool live = pair < n_pairs;
+  const int spair = live ? pair : 0;
+  const int ch = tid % C;
+  const int h = spair % nH;
+  const int b = spair / (nH * Lq);
+  const int row_stride = nH * C;
+  const size_t head_off = ((size_t)b * S * nH + h) * C + ch;
+  const T* vbase = value + head_off;
+  float* gvbase = grad_value + head_off;
+  const float* lp = loc + (size_t)spair * g.P * 2;
+  const float* ap = attn + (size_t)spair * g.P;
+  const float go = live ? VecTraits<T>::load1(grad_out + (size_t)spair * C + ch) : 0.0f;
+
+  for (int l = 0; l < g.n_levels; ++l) {
+    const int H = g.H[l], W = g.W[l], start = g.start[l];
+#pragma unroll 3
+    for (int p = g.pt_begin[l]; p < g.pt_begin[l + 1]; ++p) {
+      const float2 xy = *reinterpret_cast<const float2*>(lp + 2 * p);
+      const float a = ap[p];
+      const Corners k = make_corners(xy.x, xy.y, H, W, start);
+      const size_t o00 = (size_t)k.r00 * row_stride, o01 = (size_t)k.r01 * row_stride;
+      const size_t o10 = (size_t)k.r10 * row_stride, o11 = (size_t)k.r11 * row_stride;
+      const bool b00 = k.vx0 && k.vy0, b01 = k.vx1 && k.vy0;
+      const bool b10 = k.vx0 && k.vy1, b11 = k.vx1 && k.vy1;
+      const float v00 = b00 ? VecTraits<T>::load1(vbase + o00) : 0.0f;
+      const float v01 = b01 ? VecTraits<T>::load1(vbase + o01) : 0.0f;
+      const float v10 = b10 ? VecTraits<T>::load1(vbase + o10) : 0.0f;
+      const float v11 = b11 ? VecTraits<T>::load1(vbase + o11) : 0.0f;
+
+      // d out / d attn, d out / d loc (pixel = loc*size - 0.5  =>  d pixel / d loc = size)
+      const float sampled = k.w00 * v00 + k.w01 * v01 + k.w10 * v10 + k.w11 * v11;
+      const float dvdx = (v01 - v00) * (1.0f - k.fy) + (v11 - v10) * k.fy;
+      const float dvdy = (v10 - v00) * (1.0f - k.fx) + (v11 - v01) * k.fx;
+      const float ga = group_sum<C>(go * sampled);
+      const float gx = group_sum<C>(go * dvdx) * a * (float)W;
+      const float gy = group_sum<C>(go * dvdy) * a * (float)H;
+      if (live && ch == 0) {
+        grad_attn[(size_t)pair * g.P + p] = ga;
+        *reinterpret_cast<float2*>(grad_loc + ((size_t)pair * g.P + p) * 2) = make_float2(gx, gy);
+      }
+      // d out / d value: scatter-add, fp32, no return value.
+      const float ga_go = go * a;
+      if (live) {
+        if (b00) atomicAdd(gvbase + o00, ga_go * k.w00);
+        if (b01) atomicAdd(gvbase + o01, ga_go * k.w01);
+        if (b10) atomicAdd(gvbase + o10, ga_go * k.w10);
+        if (b11) atomicAdd(gvbase + o11, ga_go * k.w11);
+      }
+    }
+  }
+}
+
+static int make_geom(MsdaGeom* g, int S, int n_levels, const int32_t* level_hw,
+                     const int32_t* num_points) {
+  if (n_levels <= 0 || n_levels > DFINE_MAX_LEVELS) return DFINE_E_UNSUPPORTED;
+  int start = 0, p = 0;
+  g->n_levels = n_levels;
+  for (int l = 0; l < n_levels; ++l) {
+    const int H = level_hw[2 * l], W = level_hw[2 * l + 1];
+    if (H <= 0 || W <= 0 || num_points[l] <= 0) return DFINE_E_BADARG;
+    g->H[l] = H;
+    g->W[l] = W;
+    g->start[l] = start;
+    g->pt_begin[l] = p;
+    start += H * W;
+    p += num_points[l];
+  }
+  g->pt_begin[n_levels] = p;
+  g->P = p;
+  if (start != S) return DFINE_E_BADARG;  // levels must tile S exactly
+  if (p > DFINE_MAX_POINTS) return DFINE_E_UNSUPPORTED;
+  return 0;
+}
+
+template <typename T, int C>
+static int launch_fwd(const void* value, const float* loc, const float* attn, void* out,
+                      const MsdaGeom& g, int B, int S, int Lq, int nH, hipStream_t st) {
+  constexpr int LPP = C / VecTraits<T>::kElems;
+  const long long n_pairs = (long long)B * Lq * nH;
+  const long long threads = n_pairs * LPP;
+  const int block = 256;
+  const long long grid = (threads + block - 1) / block;
+  if (grid > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
+  hipLaunchKernelGGL((msda_fwd_kernel<T, C>), dim3((unsigned)grid), dim3(block), 0, st,
+                     (const T*)value, loc, attn, (T*)out, g, (int)n_pairs, S, Lq, nH);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int C>
+static int launch_bwd(const void* value, const float* loc, const float* attn,
+                      const void* grad_out, float* grad_value, float* grad_loc, float* grad_attn,
+                      const MsdaGeom& g, int B, int S, int Lq, int nH, hipStream_t st) {
+  const long long n_pairs = (long long)B * Lq * nH;
+  const long long threads = n_pairs * C;
+  const int block = 256;
+  const long long grid = (threads + block - 1) / block;
+  if (grid > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
+  hipLaunchKernelGGL((msda_bwd_kernel<T, C>), dim3((unsigned)grid), dim3(block), 0, st,
+                     (const T*)value, loc, attn, (const T*)grad_out, grad_value, grad_loc,
+                     grad_attn, g, (int)n_pairs, S, Lq, nH);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace dfine
+
+using namespace dfine;
+
+extern "C" int dfine_abi_version(void) { return DFINE_ABI_VERSION; }
+
+extern "C" int dfine_msda_fwd(const void* value, int value_dtype, const float* loc,
+                              const float* attn, void* out, int B, int S, int Lq, int nH, int c,
+                              int n_levels, const int32_t* level_hw, const int32_t* num_points,
+                              void* stream) {
+  if (!value || !loc || !attn || !out || !level_hw || !num_points) return DFINE_E_BADARG;
+  if (B <= 0 || S <= 0 || Lq <= 0 || nH <= 0) return DFINE_E_BADARG;
+  MsdaGeom g;
+  if (int rc = make_geom(&g, S, n_levels, level_hw, num_points)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (value_dtype == DFINE_DT_BF16 && c == 32)
+    return launch_fwd<bf16_t, 32>(value, loc, attn, out, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_BF16 && c == 16)
+    return launch_fwd<bf16_t, 16>(value, loc, attn, out, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_F32 && c == 32)
+    return launch_fwd<float, 32>(value, loc, attn, out, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_F32 && c == 16)
+    return launch_fwd<float, 16>(value, loc, attn, out, g, B, S, Lq, nH, st);
+  return DFINE_E_UNSUPPORTED;
+}
+
+extern "C" int dfine_msda_bwd(const void* value, int value_dtype, const float* loc,
+                              const float* attn, const void* grad_out, float* grad_value,
+                              float* grad_loc, float* grad_attn, int B, int S, int Lq, int nH,
+                              int c, int n_levels, const int32_t* level_hw,
+                              const int32_t* num_points, void* stream) {
+  if (!value || !loc || !attn || !grad_out || !grad_value || !grad_loc || !grad_attn ||
+      !level_hw || !num_points)
+    return DFINE_E_BADARG;
+  if (B <= 0 || S <= 0 || Lq <= 0 || nH <= 0) return DFINE_E_BADARG;
+  MsdaGeom g;
+  if (int rc = make_geom(&g, S, n_levels, level_hw, num_points)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (value_dtype == DFINE_DT_BF16 && c == 32)
+    return launch_bwd<bf16_t, 32>(value, loc, attn, grad_out, grad_value, grad_loc, grad_attn, g,
+                                  B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_BF16 && c == 16)
+    return launch_bwd<bf16_t, 16>(value, loc, attn, grad_out, grad_value, grad_loc, grad_attn, g,
+                                  B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_F32 && c == 32)
+    return launch_bwd<float, 32>(value, loc, attn, grad_out, grad_value, grad_loc, grad_attn, g,
+                                 B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_F32 && c == 16)
+    return launch_bwd<float, 16>(value, loc, attn, grad_out, grad_value, grad_loc, grad_attn, g,
+                                 B, S, Lq, nH, st);
+  return DFINE_E_UNSUPPORTED;
+}

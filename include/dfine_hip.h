@@ -1,0 +1,86 @@
+/*
+ * dfine_hip.h -- C ABI of libdfine_hip.so, the gfx950 (MI355X) kernels behind the
+ * D-FINE training hot path.
+ *
+ * Conventions (every entry point):
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory owned by the
+ *     caller (PyTorch's caching allocator in practice) unless the argument is documented
+ *     "host"; the library never allocates, frees or synchronises;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - returns 0 on success, a hipError_t value (>0) if a launch failed, or a negative
+ *     DFINE_E_* code when the arguments are outside what the kernels were built for
+ *     (nothing is launched in that case);
+ *   - tensors are contiguous, row-major in the index order written in the comment.
+ *
+ * The reference (uc-vision/D-FINE-seg) is pure Python; its operator seams are Python
+ * callables. Each entry point cites the reference callable (file:line under
+ * /root/reference) whose ATen op sequence it replaces.
+ */
+#ifndef DFINE_HIP_H_
+#define DFINE_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFINE_ABI_VERSION 1
+
+/* element types of `value`/`out` tensors */
+#define DFINE_DT_F32 0
+#define DFINE_DT_BF16 1
+
+/* argument errors (negative so they never collide with hipError_t) */
+#define DFINE_E_BADARG (-1)   /* null pointer / non-positive size            */
+#define DFINE_E_UNSUPPORTED (-2) /* shape or dtype the kernels are not built for */
+
+#define DFINE_MAX_LEVELS 4
+#define DFINE_MAX_POINTS 32 /* sum of points over levels, per head */
+
+int dfine_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Multi-scale deformable attention core (decoder cross-attention gather).
+ * Replaces deformable_attention_core_func_v2, method="default"
+ *   (src/d_fine/arch/utils.py:191-264; bound at src/d_fine/arch/dfine_decoder.py:90-92,
+ *    called at :174-176), i.e. per level F.grid_sample(bilinear, zeros,
+ *    align_corners=False) + weighted sum over the points.
+ *
+ * Layout difference to the reference, on purpose: `value` is the decoder memory itself,
+ * channel-last [B, S, nH, c] with S = sum_l H_l*W_l (level l starts at row sum_{k<l} H_k*W_k,
+ * row-major (y, x) inside a level). The reference permutes it to (B*nH, c, H_l, W_l) per
+ * level (dfine_decoder.py:416-426); here one bilinear corner of one head is one contiguous
+ * c*sizeof(elem) segment.
+ *
+ *   value      [B, S, nH, c]            f32 or bf16 (value_dtype)
+ *   loc        [B, Lq, nH, P, 2] f32    sampling locations (x, y) in [0,1] image coords,
+ *                                       P = sum_l num_points[l], level-major along P
+ *   attn       [B, Lq, nH, P]    f32    attention weights (already soft-maxed)
+ *   out        [B, Lq, nH*c]            same dtype as value; fp32 accumulation inside
+ *   level_hw   host int32 [n_levels][2] (H_l, W_l)
+ *   num_points host int32 [n_levels]
+ * Supported: c in {16, 32}; n_levels <= DFINE_MAX_LEVELS; P <= DFINE_MAX_POINTS.
+ * ------------------------------------------------------------------------------------- */
+int dfine_msda_fwd(const void* value, int value_dtype, const float* loc, const float* attn,
+                   void* out, int B, int S, int Lq, int nH, int c, int n_levels,
+                   const int32_t* level_hw, const int32_t* num_points, void* stream);
+
+/* Backward of the above (autograd of the same reference lines).
+ *   grad_out   [B, Lq, nH*c]            same dtype as value
+ *   grad_value [B, S, nH, c]     f32    ACCUMULATED with float atomics: the caller zeroes
+ *                                       it (or keeps accumulating several layers into it:
+ *                                       all decoder layers share one `value`,
+ *                                       dfine_decoder.py:449)
+ *   grad_loc   [B, Lq, nH, P, 2] f32    overwritten
+ *   grad_attn  [B, Lq, nH, P]    f32    overwritten
+ */
+int dfine_msda_bwd(const void* value, int value_dtype, const float* loc, const float* attn,
+                   const void* grad_out, float* grad_value, float* grad_loc, float* grad_attn,
+                   int B, int S, int Lq, int nH, int c, int n_levels, const int32_t* level_hw,
+                   const int32_t* num_points, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFINE_HIP_H_ */

@@ -1,0 +1,133 @@
+"""Deformable-attention core: oracle vs the reference's golden outputs (CPU), and the HIP
+kernels vs golden / oracle (GPU, through the C ABI)."""
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ops as oracle_ops
+
+CASES = ["small", "rect3"]
+
+
+def _case(g, name):
+    t = {k.split(".", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith(name + ".")}
+    t["shapes"] = [tuple(int(x) for x in s) for s in t["shapes"]]
+    t["num_points"] = [int(x) for x in t["num_points"]]
+    return t
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_golden(name):
+    c = _case(load_golden("msda_core"), name)
+    value, loc, attn = (c[k].clone().requires_grad_(True) for k in ("value", "loc", "attn"))
+    out = oracle_ops.deformable_attention_core(value, c["shapes"], loc, attn, c["num_points"])
+    out.backward(c["grad_out"])
+    # fp32 CPU restatement vs the reference's own output: reassociation-level differences only
+    torch.testing.assert_close(out, c["out"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(value.grad, c["grad_value"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(loc.grad, c["grad_loc"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(attn.grad, c["grad_attn"], rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _hip_fwd_bwd(value, shapes, loc, attn, npts, grad_out):
+    from dfine_seg_amd import ops
+
+    value = value.cuda().requires_grad_(True)
+    loc = loc.cuda().requires_grad_(True)
+    attn = attn.cuda().requires_grad_(True)
+    out = ops.deformable_attention_core(value, shapes, loc, attn, npts)
+    out.backward(grad_out.cuda().to(out.dtype))
+    return out.float().cpu(), value.grad.float().cpu(), loc.grad.cpu(), attn.grad.cpu()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_f32_matches_reference_golden(hip_lib, name):
+    c = _case(load_golden("msda_core"), name)
+    out, gv, gl, ga = _hip_fwd_bwd(c["value"], c["shapes"], c["loc"], c["attn"], c["num_points"], c["grad_out"])
+    # fp32 kernel, fp32 accumulate: tolerance = summation-order noise (atomics are unordered)
+    torch.testing.assert_close(out, c["out"], rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(gv, c["grad_value"], rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(gl, c["grad_loc"], rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(ga, c["grad_attn"], rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_bf16_matches_reference_golden(hip_lib, name):
+    """bf16 value/out storage, fp32 math: the only error is the bf16 rounding of value
+    (rel 2^-9) going in and of out / grad_out coming out."""
+    c = _case(load_golden("msda_core"), name)
+    out, gv, gl, ga = _hip_fwd_bwd(
+        c["value"].bfloat16(), c["shapes"], c["loc"], c["attn"], c["num_points"], c["grad_out"]
+    )
+    torch.testing.assert_close(out, c["out"], rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(gv, c["grad_value"], rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(ga, c["grad_attn"], rtol=2e-2, atol=6e-2)
+    # grad_loc is a difference of neighbouring bf16-rounded pixels times the map size
+    rel = (gl - c["grad_loc"]).norm() / c["grad_loc"].norm()
+    assert rel < 2e-2, rel
+
+
+def _random_case(B, Lq, nH, c, shapes, npts, seed, spread=1.3):
+    g = torch.Generator().manual_seed(seed)
+    S, P = sum(h * w for h, w in shapes), sum(npts)
+    value = torch.randn(B, S, nH, c, generator=g)
+    loc = torch.rand(B, Lq, nH, P, 2, generator=g) * spread - (spread - 1) / 2
+    attn = torch.softmax(torch.randn(B, Lq, nH, P, generator=g), -1)
+    grad_out = torch.randn(B, Lq, nH * c, generator=g)
+    return value, loc, attn, grad_out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize(
+    "B,Lq,nH,c,shapes,npts",
+    [
+        (2, 492, 8, 32, [(80, 80), (40, 40), (20, 20)], [3, 6, 3]),  # D-FINE-m/s @640 (BASELINE configs 1-3)
+        (2, 492, 8, 16, [(20, 20), (10, 10)], [6, 6]),  # D-FINE-n @320 (config 0)
+        (1, 300, 8, 32, [(120, 120), (60, 60), (30, 30)], [3, 6, 3]),  # D-FINE-x @960 eval queries
+        (3, 7, 1, 32, [(1, 1)], [1]),  # degenerate: one pixel, one point, ragged thread tail
+        (1, 33, 8, 32, [(5, 7), (3, 2)], [4, 4]),
+    ],
+)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hip_matches_oracle_config_shapes(hip_lib, B, Lq, nH, c, shapes, npts, dtype):
+    value, loc, attn, grad_out = _random_case(B, Lq, nH, c, shapes, npts, seed=7)
+    value = value.to(dtype)
+    grad_out = grad_out.to(dtype)
+    v = value.float().requires_grad_(True)
+    l, a = loc.clone().requires_grad_(True), attn.clone().requires_grad_(True)
+    ref = oracle_ops.deformable_attention_core(v, shapes, l, a, npts)
+    ref.backward(grad_out.float())
+    out, gv, gl, ga = _hip_fwd_bwd(value, shapes, loc, attn, npts, grad_out)
+    if dtype == torch.float32:
+        tol = dict(rtol=1e-4, atol=1e-4)
+    else:  # bf16 rounding of out (fwd) and of the value-dtype grad_value (bwd)
+        tol = dict(rtol=1.6e-2, atol=1.6e-2)
+    torch.testing.assert_close(out, ref.detach(), **tol)
+    torch.testing.assert_close(ga, a.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(gl, l.grad, rtol=1e-3, atol=1e-2 * max(max(s) for s in shapes) / 20)
+    gv_tol = tol if dtype == torch.float32 else dict(rtol=1.6e-2, atol=3e-2)
+    torch.testing.assert_close(gv, v.grad, **gv_tol)
+
+
+@pytest.mark.gpu
+def test_hip_properties_full_size(hip_lib):
+    """BASELINE full size (B=32 m@640): properties that need no oracle run.
+    (1) locations wholly outside the image gather zeros; (2) linearity in the attention
+    weights; (3) a constant map samples to sum(attn) wherever all 4 corners are inside."""
+    from dfine_seg_amd import ops
+
+    B, Lq, nH, c, shapes, npts = 32, 492, 8, 32, [(80, 80), (40, 40), (20, 20)], [3, 6, 3]
+    value, loc, attn, _ = _random_case(B, Lq, nH, c, shapes, npts, seed=11)
+    value, loc, attn = value.cuda().bfloat16(), loc.cuda(), attn.cuda()
+    out1 = ops.deformable_attention_core(value, shapes, loc, attn, npts).float()
+    out2 = ops.deformable_attention_core(value, shapes, loc, 2 * attn, npts).float()
+    torch.testing.assert_close(out2, 2 * out1, rtol=1e-2, atol=1e-2)
+    far = ops.deformable_attention_core(value, shapes, loc + 3.0, attn, npts)
+    assert float(far.float().abs().max()) == 0.0
+    ones = torch.ones_like(value)
+    inner = loc.clamp(0.1, 0.9)
+    const = ops.deformable_attention_core(ones, shapes, inner, attn, npts).float()
+    torch.testing.assert_close(const, attn.sum(-1, keepdim=True).expand(B, Lq, nH, c).reshape(B, Lq, nH * c), rtol=1e-2, atol=1e-2)
