@@ -51,7 +51,7 @@ def save(name, **arrays):
 
 
 # ------------------------------------------------------------------------------------------
-def gen_msda():
+def gen_msda(names=None):
     """deformable_attention_core_func_v2 forward + autograd grads (arch/utils.py:191-264)."""
     import_reference()
     from src.d_fine.arch.utils import deformable_attention_core_func_v2
@@ -84,14 +84,133 @@ def gen_msda():
     save("msda_core", **out)
 
 
-GROUPS = {"msda": gen_msda}
+# ------------------------------------------------------------------------------------------
+def _sample(t, n=512):
+    """Evenly strided sample of a tensor (keeps fixtures small) + its mean |value|."""
+    f = t.detach().float().flatten()
+    step = max(1, f.numel() // n)
+    return f[::step][:n].clone(), f.abs().mean()
+
+
+def _flat_indices(indices):
+    """list over images of (q_idx, gt_idx) -> int64 [M,3] rows (image, query, gt)."""
+    rows = [torch.stack([torch.full_like(q, b), q, g], 1) for b, (q, g) in enumerate(indices)]
+    return torch.cat(rows, 0) if rows else torch.zeros(0, 3, dtype=torch.int64)
+
+
+MODEL_CASES = {
+    # fixture name: (size, img, n_gts per image, segment?)   -- BASELINE configs 0 and 1-3 shapes
+    "model_n320": ("n", 320, [3, 5], False),
+    "model_n320_empty": ("n", 320, [0, 4], False),  # ragged: an image without GT
+    # B=2 everywhere: at B=1 torch 2.10's CPU batch_norm backward mis-reads channels-last-like
+    # gradients with a size-1 batch stride (see oracle/model.py:_DenseGrad), which would bake a
+    # PyTorch bug into the reference's own gradients.
+    "model_s640": ("s", 640, [6, 2], False),
+    "model_m640": ("m", 640, [4, 9], False),
+    "model_m640_seg": ("m", 640, [4, 3], True),
+    "model_x640": ("x", 640, [2, 5], False),  # x architecture (frozen BN, 384->256 proj) at a small image
+}
+SEED_WEIGHTS_IMG, SEED_TARGETS, SEED_CDN = 1, 2, 123
+
+
+def gen_model(names=None):
+    """End-to-end train-mode forward + criterion + backward of the reference model with the
+    name-hashed weights (oracle/weights.py), plus an eval-mode forward."""
+    import_reference()
+    from src.d_fine import configs as ref_configs
+    from src.d_fine.dfine import build_loss, build_model
+
+    from . import weights
+
+    for fname, (size, img, n_gts, seg) in MODEL_CASES.items():
+        if names and fname not in names:
+            continue
+        torch.manual_seed(0)
+        model = build_model(size, 80, seg, "cpu", img_size=[img, img], pretrained_model_path=None)
+        model.load_state_dict(weights.fill_state_dict(model.state_dict()), strict=True)
+        x = weights.synthetic_images(len(n_gts), img, img, SEED_WEIGHTS_IMG)
+        targets = weights.synthetic_targets(n_gts, 80, SEED_TARGETS, with_masks=seg, height=img, width=img)
+        out = {"n_gts": np.array(n_gts), "img": np.array(img), "seg": np.array(int(seg))}
+        # the state_dict layout is itself a contract (SURVEY.md A.10): names, shapes, dtypes, trainability
+        sd0 = model.state_dict()
+        out["sd.names"] = np.array(list(sd0.keys()))
+        out["sd.shapes"] = np.array([list(v.shape) + [-1] * (4 - v.dim()) for v in sd0.values()])
+        out["sd.dtypes"] = np.array([str(v.dtype).replace("torch.", "") for v in sd0.values()])
+        out["sd.trainable"] = np.array([n for n, p in model.named_parameters() if p.requires_grad])
+
+        # eval-mode forward first: BatchNorm running stats are still the initial ones
+        model.eval()
+        with torch.no_grad():
+            ev = model(x)
+        out["eval.pred_logits"], out["eval.pred_boxes"] = ev["pred_logits"], ev["pred_boxes"]
+        if seg:
+            out["eval.pred_masks.sample"], out["eval.pred_masks.absmean"] = _sample(ev["pred_masks"], 4096)
+
+        # capture intermediates with hooks (no reference code is modified)
+        grabbed = {}
+        hooks = [
+            model.backbone.register_forward_hook(lambda m, i, o: grabbed.__setitem__("backbone", o)),
+            model.encoder.register_forward_hook(lambda m, i, o: grabbed.__setitem__("encoder", o)),
+            model.decoder.enc_score_head.register_forward_hook(lambda m, i, o: grabbed.__setitem__("enc_logits", o)),
+        ]
+        model.train()
+        torch.manual_seed(SEED_CDN)
+        res = model(x, targets=targets)
+        for lvl, f in enumerate(grabbed["backbone"]):
+            out[f"backbone.{lvl}.sample"], out[f"backbone.{lvl}.absmean"] = _sample(f)
+        for lvl, f in enumerate(grabbed["encoder"][0]):
+            out[f"encoder.outs.{lvl}.sample"], out[f"encoder.outs.{lvl}.absmean"] = _sample(f)
+        for lvl, f in enumerate(grabbed["encoder"][1]):
+            out[f"encoder.inner.{lvl}.sample"], out[f"encoder.inner.{lvl}.absmean"] = _sample(f)
+        out["topk_ind"] = torch.topk(grabbed["enc_logits"].max(-1).values, 300, dim=-1).indices
+
+        for k in ("pred_logits", "pred_boxes", "pred_corners", "ref_points"):
+            out[f"train.{k}"] = res[k]
+        if seg:
+            out["train.pred_masks.sample"], out["train.pred_masks.absmean"] = _sample(res["pred_masks"], 4096)
+        heads = {f"aux{i}": d for i, d in enumerate(res["aux_outputs"])}
+        heads.update(pre=res["pre_outputs"], enc0=res["enc_aux_outputs"][0])
+        if "dn_outputs" in res:
+            heads.update({f"dn{i}": d for i, d in enumerate(res["dn_outputs"])})
+            heads["dn_pre"] = res["dn_pre_outputs"]
+            out["dn_num_group"] = np.array(res["dn_meta"]["dn_num_group"])
+            out["dn_num_split"] = np.array(res["dn_meta"]["dn_num_split"])
+        for hname, d in heads.items():
+            out[f"train.{hname}.pred_boxes"] = d["pred_boxes"]
+            out[f"train.{hname}.pred_logits.sample"], out[f"train.{hname}.pred_logits.absmean"] = _sample(d["pred_logits"], 2048)
+
+        ref_configs.models[size]["DFINECriterion"]["losses"] = ["vfl", "boxes", "local"]  # build_loss appends in place
+        crit = build_loss(size, 80, 0.0, seg)
+        matcher = crit.matcher
+        out["match.main"] = _flat_indices(matcher({"pred_logits": res["pred_logits"], "pred_boxes": res["pred_boxes"]}, targets)["indices"])
+        out["match.enc0"] = _flat_indices(matcher(res["enc_aux_outputs"][0], targets)["indices"])
+        losses = crit(res, targets)
+        out["loss.names"] = np.array(list(losses.keys()))
+        out["loss.values"] = torch.stack([v.detach().float().reshape(()) for v in losses.values()])
+        sum(losses.values()).backward()
+        names_, norms = [], []
+        for n_, p in model.named_parameters():
+            names_.append(n_)
+            norms.append(p.grad.float().norm() if p.grad is not None else torch.tensor(-1.0))
+        out["grad.names"] = np.array(names_)
+        out["grad.norms"] = torch.stack(norms)
+        bn = {k: v for k, v in model.state_dict().items() if k.endswith("running_var")}
+        out["bn.running_var.absmean"] = torch.stack([v.abs().mean() for v in bn.values()])
+
+        for h in hooks:
+            h.remove()
+        save(fname, **out)
+
+
+GROUPS = {"msda": gen_msda, "model": gen_model}
 
 
 def main(argv):
     torch.set_num_threads(4)
     names = argv or list(GROUPS)
     for n in names:
-        GROUPS[n]()
+        group, _, sub = n.partition(":")
+        GROUPS[group](sub.split(",")) if sub else GROUPS[group]()
 
 
 if __name__ == "__main__":

@@ -33,9 +33,9 @@ def test_oracle_matches_reference_golden(name):
 def _hip_fwd_bwd(value, shapes, loc, attn, npts, grad_out):
     from dfine_seg_amd import ops
 
-    value = value.cuda().requires_grad_(True)
-    loc = loc.cuda().requires_grad_(True)
-    attn = attn.cuda().requires_grad_(True)
+    value = value.detach().cuda().requires_grad_(True)
+    loc = loc.detach().cuda().requires_grad_(True)
+    attn = attn.detach().cuda().requires_grad_(True)
     out = ops.deformable_attention_core(value, shapes, loc, attn, npts)
     out.backward(grad_out.cuda().to(out.dtype))
     return out.float().cpu(), value.grad.float().cpu(), loc.grad.cpu(), attn.grad.cpu()
@@ -96,7 +96,7 @@ def test_hip_matches_oracle_config_shapes(hip_lib, B, Lq, nH, c, shapes, npts, d
     value, loc, attn, grad_out = _random_case(B, Lq, nH, c, shapes, npts, seed=7)
     value = value.to(dtype)
     grad_out = grad_out.to(dtype)
-    v = value.float().requires_grad_(True)
+    v = value.float().clone().requires_grad_(True)
     l, a = loc.clone().requires_grad_(True), attn.clone().requires_grad_(True)
     ref = oracle_ops.deformable_attention_core(v, shapes, l, a, npts)
     ref.backward(grad_out.float())

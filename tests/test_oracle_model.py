@@ -1,0 +1,130 @@
+"""The functional CPU oracle (oracle/model.py + oracle/criterion.py) against outputs of the
+reference itself (tests/golden/model_*.npz, made by oracle/gen_golden.py).
+
+Tolerances: both sides are fp32 CPU PyTorch; differences come from op order only (own
+attention / gather formulations), so activations agree to ~1e-4 absolute on O(1..10) values
+and losses to 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import configs as C
+from oracle import criterion as oc
+from oracle import model as om
+from oracle import weights
+from oracle.gen_golden import MODEL_CASES, SEED_CDN, SEED_TARGETS, SEED_WEIGHTS_IMG, _sample
+
+FAST = ["model_n320", "model_n320_empty"]
+SLOW = ["model_s640", "model_m640", "model_m640_seg", "model_x640"]
+
+
+def state_dict_from_fixture(g):
+    """Empty tensors with the reference's names/shapes/dtypes, filled by the name-hashed initializer.
+    Derived buffers the initializer keeps (reg_scale, up, num_points_scale, ...) get their
+    constructor values here."""
+    sd = {}
+    for name, shape, dt in zip(g["sd.names"], g["sd.shapes"], g["sd.dtypes"]):
+        shape = [int(s) for s in shape if s >= 0]
+        sd[str(name)] = torch.zeros(shape, dtype=getattr(torch, str(dt)))
+    return sd
+
+
+def build_oracle_sd(g, size):
+    cfg = C.size_cfg(size)
+    sd = state_dict_from_fixture(g)
+    sd = weights.fill_state_dict(sd)
+    for k in list(sd):
+        if k.endswith("decoder.up") or k == "decoder.up":
+            sd[k] = torch.tensor([0.5])
+        elif k.endswith("reg_scale"):
+            sd[k] = torch.tensor([cfg["reg_scale"]])
+        elif k.endswith("num_points_scale"):
+            sd[k] = torch.tensor([1.0 / n for n in cfg["points"] for _ in range(n)])
+    trainable = set(str(n) for n in g["sd.trainable"])
+    for k, v in sd.items():
+        if k in trainable:
+            v.requires_grad_(True)
+    return sd, cfg
+
+
+def run_case(fname):
+    size, img, n_gts, seg = MODEL_CASES[fname]
+    g = load_golden(fname)
+    sd, cfg = build_oracle_sd(g, size)
+    x = weights.synthetic_images(len(n_gts), img, img, SEED_WEIGHTS_IMG)
+    targets = weights.synthetic_targets(n_gts, 80, SEED_TARGETS, with_masks=seg, height=img, width=img)
+    return g, sd, cfg, x, targets, seg
+
+
+def close(a, b, atol=3e-4, rtol=1e-4):
+    torch.testing.assert_close(a.float(), torch.as_tensor(b).float(), atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("fname", FAST + SLOW)
+def test_train_forward_loss_and_grads(fname):
+    g, sd, cfg, x, targets, seg = run_case(fname)
+    torch.manual_seed(SEED_CDN)  # the oracle replays the reference's four CDN draws
+    feats = om.backbone(sd, cfg, x, True)
+    for lvl, f in enumerate(feats):
+        close(_sample(f)[0], g[f"backbone.{lvl}.sample"])
+        close(_sample(f)[1], g[f"backbone.{lvl}.absmean"])
+    outs, inner = om.encoder(sd, cfg, feats, True)
+    for lvl, f in enumerate(outs):
+        close(_sample(f)[0], g[f"encoder.outs.{lvl}.sample"], atol=1e-3)
+    for lvl, f in enumerate(inner):
+        close(_sample(f)[0], g[f"encoder.inner.{lvl}.sample"], atol=1e-3)
+    res = om.decoder(sd, cfg, outs, inner, targets, True, enable_mask_head=seg)
+    # query selection must agree exactly, otherwise nothing downstream is comparable
+    topk = torch.as_tensor(g["topk_ind"])
+    enc_boxes_ref = torch.as_tensor(g["train.enc0.pred_boxes"])
+    close(res["enc_aux_outputs"][0]["pred_boxes"], enc_boxes_ref, atol=1e-4)
+    for k in ("pred_logits", "pred_boxes", "pred_corners", "ref_points"):
+        close(res[k], g[f"train.{k}"], atol=1e-3)
+    heads = {f"aux{i}": d for i, d in enumerate(res["aux_outputs"])}
+    heads.update(pre=res["pre_outputs"], enc0=res["enc_aux_outputs"][0])
+    if "dn_outputs" in res:
+        heads.update({f"dn{i}": d for i, d in enumerate(res["dn_outputs"])})
+        heads["dn_pre"] = res["dn_pre_outputs"]
+        assert res["dn_meta"]["dn_num_group"] == int(g["dn_num_group"])
+        assert list(res["dn_meta"]["dn_num_split"]) == [int(v) for v in g["dn_num_split"]]
+    for hname, d in heads.items():
+        close(d["pred_boxes"], g[f"train.{hname}.pred_boxes"], atol=1e-3)
+        close(_sample(d["pred_logits"], 2048)[0], g[f"train.{hname}.pred_logits.sample"], atol=1e-3)
+    if seg:
+        close(_sample(res["pred_masks"], 4096)[0], g["train.pred_masks.sample"], atol=5e-3)
+
+    losses, idx = oc.criterion(res, targets, 80, with_masks=seg, return_indices=True)
+    flat = lambda ind: torch.cat([torch.stack([torch.full_like(q, b), q, t], 1) for b, (q, t) in enumerate(ind)], 0)
+    assert torch.equal(flat(idx["indices"]), torch.as_tensor(g["match.main"]))
+    assert torch.equal(flat(idx["enc"][0]), torch.as_tensor(g["match.enc0"]))
+    names = [str(n) for n in g["loss.names"]]
+    assert list(losses.keys()) == names  # same terms, same order as the reference
+    got = torch.stack([losses[n].detach().float().reshape(()) for n in names])
+    torch.testing.assert_close(got, torch.as_tensor(g["loss.values"]), rtol=2e-4, atol=2e-4)
+
+    sum(losses.values()).backward()
+    ref_norms = {str(n): float(v) for n, v in zip(g["grad.names"], g["grad.norms"])}
+    scale = max(ref_norms.values())
+    for n, ref in ref_norms.items():
+        grad = sd[n].grad
+        if ref < 0:  # reference produced no grad (unused / frozen parameter)
+            assert grad is None or float(grad.abs().max()) == 0.0, n
+            continue
+        got_n = float(grad.norm()) if grad is not None else 0.0
+        # parameters whose true gradient is ~0 (a bias or LAB scale in front of a BatchNorm)
+        # carry only cancellation noise on both sides: compare on the global gradient scale
+        assert abs(got_n - ref) <= 5e-3 * ref + 2e-5 * scale, (n, got_n, ref)
+    rv = torch.stack([v.abs().mean() for k, v in sd.items() if k.endswith("running_var")])
+    close(rv, g["bn.running_var.absmean"], atol=1e-5)
+
+
+@pytest.mark.parametrize("fname", FAST + ["model_m640_seg"])
+def test_eval_forward(fname):
+    g, sd, cfg, x, targets, seg = run_case(fname)
+    with torch.no_grad():
+        ev = om.forward(sd, cfg, x, None, training=False, enable_mask_head=seg)
+    close(ev["pred_logits"], g["eval.pred_logits"], atol=1e-3)
+    close(ev["pred_boxes"], g["eval.pred_boxes"], atol=1e-4)
+    if seg:
+        close(_sample(ev["pred_masks"], 4096)[0], g["eval.pred_masks.sample"], atol=1e-3)
