@@ -20,6 +20,9 @@ SIGNATURES = {
     + [_c_int] * 6
     + [_i32p, _i32p, _c_void_p],
     "dfine_msda_bwd": [_c_void_p, _c_int] + [_c_void_p] * 6 + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
+    "dfine_match_cost": [_c_void_p] * 6 + [_c_int] * 5 + [ctypes.c_float] * 5 + [_c_void_p],
+    "dfine_lsap": [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p],
+    "dfine_go_union": [_c_void_p] * 2 + [_c_int] * 3 + [_c_void_p],
 }
 
 ABI_VERSION = 1

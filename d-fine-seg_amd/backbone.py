@@ -1,0 +1,93 @@
+"""HGNetv2 backbone, channel-last. Structure and parameter names after the reference's
+src/d_fine/arch/hgnetv2.py (stem :115-166, HG_Block :189-275 with the default ``agg="se"``
+aggregation, HG_Stage :278-329); the unused ESE / padding="same" branches are not built.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .configs import BACKBONES, ModelSpec
+from .layers import ConvNorm
+
+
+class Stem(nn.Module):
+    def __init__(self, c_in, c_mid, c_out, kw):
+        super().__init__()
+        self.stem1 = ConvNorm(c_in, c_mid, 3, stride=2, **kw)
+        self.stem2a = ConvNorm(c_mid, c_mid // 2, 2, **kw)
+        self.stem2b = ConvNorm(c_mid // 2, c_mid, 2, **kw)
+        self.stem3 = ConvNorm(c_mid * 2, c_mid, 3, stride=2, **kw)
+        self.stem4 = ConvNorm(c_mid, c_out, 1, **kw)
+
+    def forward(self, x):
+        x = F.pad(self.stem1(x), (0, 1, 0, 1))  # right/bottom pad so the 2x2 convs keep H, W
+        branch = self.stem2b(F.pad(self.stem2a(x), (0, 1, 0, 1)))
+        pooled = F.max_pool2d(x, 2, stride=1, ceil_mode=True)
+        return self.stem4(self.stem3(torch.cat([pooled, branch], 1)))
+
+
+class LightConv(nn.Module):
+    """1x1 conv+norm (no act) then depthwise kxk conv+norm+act (hgnetv2.py:83-112)."""
+
+    def __init__(self, c_in, c_out, k, kw):
+        super().__init__()
+        self.conv1 = ConvNorm(c_in, c_out, 1, **{**kw, "act": None})
+        self.conv2 = ConvNorm(c_out, c_out, k, groups=c_out, **kw)
+
+    def forward(self, x):
+        return self.conv2(self.conv1(x))
+
+
+class Block(nn.Module):
+    def __init__(self, c_in, c_mid, c_out, n_layers, k, light, residual, kw):
+        super().__init__()
+        make = (lambda ci: LightConv(ci, c_mid, k, kw)) if light else (lambda ci: ConvNorm(ci, c_mid, k, **kw))
+        self.layers = nn.ModuleList(make(c_in if i == 0 else c_mid) for i in range(n_layers))
+        total = c_in + n_layers * c_mid
+        self.aggregation = nn.Sequential(ConvNorm(total, c_out // 2, 1, **kw), ConvNorm(c_out // 2, c_out, 1, **kw))
+        self.residual = residual
+
+    def forward(self, x):
+        feats = [x]
+        for layer in self.layers:
+            feats.append(layer(feats[-1]))
+        y = self.aggregation(torch.cat(feats, 1))
+        return y + x if self.residual else y
+
+
+class Stage(nn.Module):
+    def __init__(self, s, kw):
+        super().__init__()
+        if s.downsample:  # depthwise 3x3 stride 2 + norm, no activation
+            self.downsample = ConvNorm(s.c_in, s.c_in, 3, stride=2, groups=s.c_in, **{**kw, "act": None})
+        self.blocks = nn.Sequential(*[
+            Block(s.c_in if i == 0 else s.c_out, s.c_mid, s.c_out, s.n_layers, s.kernel, s.light, i > 0, kw)
+            for i in range(s.n_blocks)
+        ])
+
+    def forward(self, x):
+        if hasattr(self, "downsample"):
+            x = self.downsample(x)
+        return self.blocks(x)
+
+
+class HGNetv2(nn.Module):
+    def __init__(self, spec: ModelSpec):
+        super().__init__()
+        arch = BACKBONES[spec.backbone]
+        kw = dict(act="relu", lab=spec.use_lab, norm_name="bn", frozen_norm=spec.frozen_backbone_norm)
+        self.stem = Stem(*arch.stem, kw)
+        self.stages = nn.ModuleList(Stage(s, kw) for s in arch.stages)
+        self.return_idx = tuple(spec.return_idx)
+        if spec.frozen_backbone_norm:  # freeze_at=0 with freeze_stem_only: the stem does not train
+            for p in self.stem.parameters():
+                p.requires_grad_(False)
+
+    def forward(self, x):
+        x = self.stem(x)
+        outs = []
+        for i, stage in enumerate(self.stages):
+            x = stage(x)
+            if i in self.return_idx:
+                outs.append(x)
+        return outs

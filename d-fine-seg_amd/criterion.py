@@ -1,0 +1,255 @@
+"""D-FINE criterion for the MI355X build: same loss terms, weights and key names as the
+reference's DFINECriterion (src/d_fine/dfine_criterion.py:410-578), restructured so a step
+never synchronises with the host:
+
+  * all L+2 Hungarian matchings run in two HIP launches (ops.hungarian_match), the GO union
+    in a third (ops.go_union); the reference does L+2 ``.cpu()`` copies + scipy calls;
+  * matchings are kept dense -- ``assign[b, q]`` = matched ground-truth index or -1 -- and every
+    loss is a masked reduction over fixed shapes ([B, Q, ...]), instead of gathers by
+    data-dependent index lists (``pred[idx]``, ``nonzero``, ``.item()``);
+  * ``num_boxes`` / ``num_boxes_go`` stay on the device and are all-reduced together as one
+    2-float message (the reference issues two all-reduces and two ``.item()``).
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .configs import CriterionSpec
+from .decoder import weighting_function
+from .targets import TargetBatch
+
+_DUMMY_BOX = (0.5, 0.5, 1.0, 1.0)  # stands in for "no target" so IoU/GIoU stay finite before masking
+
+
+def _xyxy(b):
+    cx, cy, w, h = b.unbind(-1)
+    w, h = w.clamp(min=0), h.clamp(min=0)
+    return cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h
+
+
+def paired_iou_giou(a, b):
+    """Element-wise IoU and GIoU of cxcywh boxes a, b [..., 4] (arch/utils.py:12-51, diagonal only)."""
+    ax0, ay0, ax1, ay1 = _xyxy(a)
+    bx0, by0, bx1, by1 = _xyxy(b)
+    inter = (torch.min(ax1, bx1) - torch.max(ax0, bx0)).clamp(min=0) * (torch.min(ay1, by1) - torch.max(ay0, by0)).clamp(min=0)
+    union = (ax1 - ax0) * (ay1 - ay0) + (bx1 - bx0) * (by1 - by0) - inter
+    iou = inter / union
+    hull = (torch.max(ax1, bx1) - torch.min(ax0, bx0)).clamp(min=0) * (torch.max(ay1, by1) - torch.min(ay0, by0)).clamp(min=0)
+    return iou, iou - (hull - union) / hull
+
+
+class _Matched:
+    """Dense view of one matching: for every (image, query) the matched GT's box/label, or a
+    dummy where unmatched."""
+
+    def __init__(self, assign, tb: TargetBatch, num_classes):
+        self.mask = assign >= 0  # [B, Q]
+        idx = assign.clamp(min=0).long()
+        box = tb.boxes.gather(1, idx.unsqueeze(-1).expand(-1, -1, 4))
+        self.boxes = torch.where(self.mask.unsqueeze(-1), box, box.new_tensor(_DUMMY_BOX))
+        self.labels = torch.where(self.mask, tb.labels.gather(1, idx), num_classes)
+
+
+class DFINECriterion(nn.Module):
+    def __init__(self, spec: CriterionSpec = None, num_classes=80, losses=("vfl", "boxes", "local"), label_smoothing=0.0):
+        super().__init__()
+        self.spec = spec or CriterionSpec()
+        self.num_classes = num_classes
+        self.losses = tuple(losses)
+        self.weight_dict = dict(self.spec.weight_dict)
+        self.label_smoothing = label_smoothing  # only used by the reference's inactive focal loss
+
+    # ------------------------------------------------------------------ loss terms (dense)
+    def loss_vfl(self, out, m: _Matched, num_boxes):
+        """Varifocal loss, dfine_criterion.py:92-122."""
+        logits = out["pred_logits"].float()
+        iou = paired_iou_giou(out["pred_boxes"].float(), m.boxes)[0].detach() * m.mask
+        onehot = F.one_hot(m.labels, self.num_classes + 1)[..., :-1]
+        target = iou.unsqueeze(-1) * onehot
+        p = torch.sigmoid(logits).detach()
+        weight = self.spec.alpha * p.pow(self.spec.gamma) * (1 - onehot) + target
+        loss = F.binary_cross_entropy_with_logits(logits, target, weight=weight, reduction="sum")
+        return {"loss_vfl": loss / num_boxes}
+
+    def loss_boxes(self, out, m: _Matched, num_boxes):
+        """L1 + GIoU on matched pairs, dfine_criterion.py:124-143."""
+        src = out["pred_boxes"].float()
+        l1 = ((src - m.boxes).abs().sum(-1) * m.mask).sum()
+        giou = paired_iou_giou(src, m.boxes)[1]
+        return {"loss_bbox": l1 / num_boxes, "loss_giou": ((1 - giou) * m.mask).sum() / num_boxes}
+
+    def _fgl_targets(self, ref, tgt_boxes, fdr):
+        """bbox2distance + translate_gt (arch/utils.py:267-354), element-wise over [B, Q, 4 edges]."""
+        reg_max = self.spec.reg_max
+        W, rs = fdr["W"], fdr["reg_scale"]
+        x0, y0, x1, y1 = _xyxy(tgt_boxes)
+        wq, hq = ref[..., 2] / rs + 1e-16, ref[..., 3] / rs + 1e-16
+        d = torch.stack([(ref[..., 0] - x0) / wq, (ref[..., 1] - y0) / hq, (x1 - ref[..., 0]) / wq, (y1 - ref[..., 1]) / hq], -1) - 0.5 * rs
+        idx = (W <= d.unsqueeze(-1)).sum(-1) - 1  # index of the closest bin on the left
+        inside = (idx >= 0) & (idx < reg_max)
+        li = idx.clamp(0, reg_max - 1)
+        dl, dr = (d - W[li]).abs(), (W[li + 1] - d).abs()
+        w_right = torch.where(inside, dl / (dl + dr), (idx >= reg_max).to(d.dtype))
+        w_left = torch.where(inside, 1.0 - w_right, (idx < 0).to(d.dtype))
+        left = torch.where(idx >= reg_max, reg_max - 1, li)  # reg_max-0.1 truncates to reg_max-1
+        return left, w_left, w_right
+
+    def loss_local(self, out, m: _Matched, num_boxes, cache, is_dn):
+        """FGL + DDF, dfine_criterion.py:145-237 (T = 5)."""
+        if "pred_corners" not in out:
+            return {}
+        nb, T = self.spec.reg_max + 1, self.spec.ddf_temperature
+        corners = out["pred_corners"].float()
+        B, Q = corners.shape[:2]
+        corners = corners.view(B, Q, 4, nb)
+        edge_mask = m.mask.unsqueeze(-1)
+        iou = paired_iou_giou(out["pred_boxes"].float(), m.boxes)[0].detach()
+        key = "fgl_dn" if is_dn else "fgl"
+        if key not in cache:  # from the first head of the group, reused by the others (:157-176)
+            cache[key] = self._fgl_targets(out["ref_points"].float().detach(), m.boxes, cache["fdr"])
+        left, w_left, w_right = cache[key]
+        logp = F.log_softmax(corners, dim=-1)
+        ce = -(logp.gather(-1, left.unsqueeze(-1)).squeeze(-1) * w_left + logp.gather(-1, (left + 1).unsqueeze(-1)).squeeze(-1) * w_right)
+        losses = {"loss_fgl": (ce * iou.unsqueeze(-1) * edge_mask).sum() / num_boxes}
+
+        teacher = out.get("teacher_corners")
+        if teacher is not None:
+            if out.get("self_distilled"):  # a layer distilled from itself: exactly zero (:197-198)
+                losses["loss_ddf"] = corners.sum() * 0
+                return losses
+            t_prob = F.softmax(teacher.float().detach().view(B, Q, 4, nb) / T, dim=-1)
+            kl = F.kl_div(F.log_softmax(corners / T, dim=-1), t_prob, reduction="none").sum(-1)  # [B,Q,4]
+            w = torch.where(m.mask, iou, out["teacher_logits"].float().detach().sigmoid().max(-1).values)
+            per_edge = w.unsqueeze(-1) * (T**2) * kl
+            n_pos_edges = edge_mask.sum() * 4.0
+            n_neg_edges = B * Q * 4.0 - n_pos_edges
+            if not is_dn:  # cached for the dn heads of the same step (:223-230)
+                scale = 8.0 / B
+                cache["num_pos"], cache["num_neg"] = (n_pos_edges * scale).sqrt(), (n_neg_edges * scale).sqrt()
+            pos = (per_edge * edge_mask).sum() / n_pos_edges.clamp(min=1)
+            neg = (per_edge * ~edge_mask).sum() / n_neg_edges.clamp(min=1)
+            losses["loss_ddf"] = (pos * cache["num_pos"] + neg * cache["num_neg"]) / (cache["num_pos"] + cache["num_neg"])
+        return losses
+
+    def loss_masks(self, out, pairs, tb: TargetBatch, cache):
+        """Focal-BCE + dice on the matched queries only, dfine_criterion.py:272-357.
+        pairs = (image idx, query idx, gt idx) int64 [M] each."""
+        if "pred_masks" not in out:
+            return {}
+        pm = out["pred_masks"]
+        Hm, Wm = pm.shape[-2:]
+        b, q, g = pairs
+        if b.numel() == 0 or tb.masks is None:
+            z = pm.sum() * 0
+            return {"loss_mask_bce": z, "loss_mask_dice": z}
+        if "mask_targets" not in cache:
+            cache["mask_targets"] = tb.mask_targets(Hm, Wm, pm.device)[0]
+        pred = pm[b, q].float()
+        tgt = cache["mask_targets"][b, g]
+        fg = tgt.flatten(1).mean(1).view(-1, 1, 1)
+        alpha = 0.5 + 0.25 * (1 - 2 * fg).clamp(-1, 1)
+        p = torch.sigmoid(pred)
+        bce = F.binary_cross_entropy_with_logits(pred, tgt, reduction="none")
+        p_t = p * tgt + (1 - p) * (1 - tgt)
+        focal = ((alpha * tgt + (1 - alpha) * (1 - tgt)) * (1 - p_t) ** 2 * bce).mean((1, 2)).mean()
+        pf, tf = p.flatten(1), tgt.flatten(1)
+        dice = (1.0 - (2.0 * (pf * tf).sum(1) + 1e-6) / (pf.sum(1) + tf.sum(1) + 1e-6)).mean()
+        return {"loss_mask_bce": focal, "loss_mask_dice": dice}
+
+    # ------------------------------------------------------------------ forward
+    @staticmethod
+    def _host_pairs(num_gts, device):
+        """(image, gt) index of every real ground truth, built on the host from the counts."""
+        b = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(num_gts)] or [torch.zeros(0, dtype=torch.int64)])
+        g = torch.cat([torch.arange(n, dtype=torch.int64) for n in num_gts] or [torch.zeros(0, dtype=torch.int64)])
+        return b.to(device, non_blocking=True), g.to(device, non_blocking=True)
+
+    def forward(self, outputs, targets=None):
+        spec, C = self.spec, self.num_classes
+        dev = outputs["pred_logits"].device
+        tb = outputs.get("targets")
+        if tb is None:
+            tb = TargetBatch.from_list(targets, C, dev)
+        aux, enc = outputs["aux_outputs"], outputs["enc_aux_outputs"]
+        main = {k: outputs[k] for k in ("pred_logits", "pred_boxes", "pred_corners", "ref_points", "up", "reg_scale", "pred_masks") if k in outputs}
+        heads = [main] + list(aux) + [outputs["pre_outputs"]] + list(enc)
+        # ---- all matchings of the step at once (matcher.py:52-130 x (L+2))
+        logits = torch.stack([h["pred_logits"].detach().float() for h in heads])
+        boxes = torch.stack([h["pred_boxes"].detach().float() for h in heads])
+        gt_of_query, query_of_gt = ops.hungarian_match(
+            logits, boxes, tb.labels, tb.boxes, tb.counts, spec.match_alpha, spec.match_gamma,
+            spec.cost_class, spec.cost_bbox, spec.cost_giou)
+        go = ops.go_union(gt_of_query)
+        # ---- normalisers: one 2-float all-reduce (dfine_criterion.py:436-453 issues two)
+        norm = torch.stack([(go >= 0).sum().float(), torch.tensor(float(tb.total), device=dev)])
+        world = 1
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(norm)
+            world = dist.get_world_size()
+        norm = (norm / world).clamp(min=1)
+        num_boxes_go, num_boxes = norm[0], norm[1]
+
+        m_go = _Matched(go, tb, C)
+        fdr = outputs.get("fdr")
+        if fdr is None:  # outputs not produced by this package's decoder: read the Parameters (one sync)
+            fdr = {"W": weighting_function(spec.reg_max, outputs["up"], outputs["reg_scale"]).to(dev),
+                   "reg_scale": float(outputs["reg_scale"].detach().abs().reshape(-1)[0])}
+        cache, losses = {"fdr": fdr}, {}
+        with_masks = "masks" in self.losses
+        pairs_bg = self._host_pairs(tb.num_gts, dev) if with_masks else None
+
+        def add(out, suffix, own, own_idx, use_go=("boxes", "local"), is_dn=False, nb_own=num_boxes, nb_go=num_boxes_go):
+            res = {}
+            for name in self.losses:
+                m, nb = (m_go, nb_go) if (name in use_go) else (own, nb_own)
+                if name == "vfl":
+                    res.update(self.loss_vfl(out, m, nb))
+                elif name == "boxes":
+                    res.update(self.loss_boxes(out, m, nb))
+                elif name == "local":
+                    res.update(self.loss_local(out, m, nb, cache, is_dn))
+                elif name == "masks":
+                    res.update(self.loss_masks(out, own_idx, tb, cache))
+            losses.update({k + suffix: v * self.weight_dict[k] for k, v in res.items() if k in self.weight_dict})
+
+        def own_of(h):
+            pairs = None
+            if with_masks:
+                b, g = pairs_bg
+                pairs = (b, query_of_gt[h].long()[b, g], g)
+            return _Matched(gt_of_query[h], tb, C), pairs
+
+        shared = {"up": outputs["up"], "reg_scale": outputs["reg_scale"]}
+        add(main, "", *own_of(0))
+        for i, out in enumerate(aux):
+            add({**out, **shared}, f"_aux_{i}", *own_of(1 + i))
+        add(outputs["pre_outputs"], "_pre", *own_of(1 + len(aux)))
+        for i, out in enumerate(enc):
+            add(out, f"_enc_{i}", *own_of(2 + len(aux) + i), use_go=("boxes",))
+
+        if "dn_outputs" in outputs:
+            meta = outputs["dn_meta"]
+            groups = meta["dn_num_group"]
+            dn_nb = num_boxes * groups if groups > 0 else num_boxes.new_tensor(1.0)
+            dn_nb = torch.where(dn_nb > 0, dn_nb, torch.ones_like(dn_nb))
+            assign = meta["dn_assign"]
+            if assign is None:
+                assign = torch.full(outputs["dn_pre_outputs"]["pred_logits"].shape[:2], -1, dtype=torch.int32, device=dev)
+            m_dn = _Matched(assign, tb, C)
+            dn_pairs = None
+            if with_masks:
+                G = max(tb.num_gts) if tb.total else 1
+                b, g = pairs_bg
+                reps = torch.arange(max(groups, 0), device=dev)
+                dn_pairs = (b.repeat(max(groups, 0)), (reps[:, None] * 2 * G + g[None, :]).flatten(), g.repeat(max(groups, 0)))
+            dn_kw = dict(use_go=(), is_dn=True, nb_own=dn_nb)
+            for i, out in enumerate(outputs["dn_outputs"]):
+                add({**out, **shared}, f"_dn_{i}", m_dn, dn_pairs, **dn_kw)
+            if "dn_pred_masks" in outputs and with_masks:
+                res = self.loss_masks({"pred_masks": outputs["dn_pred_masks"]}, dn_pairs, tb, cache)
+                losses.update({k + "_dn_final": v * self.weight_dict[k] for k, v in res.items()})
+            add(outputs["dn_pre_outputs"], "_dn_pre", m_dn, dn_pairs, **dn_kw)
+
+        return {k: torch.nan_to_num(v, nan=0.0) for k, v in losses.items()}

@@ -1,0 +1,396 @@
+"""D-FINE transformer decoder: query selection, contrastive denoising queries, decoder layers
+(self-attention, multi-scale deformable cross-attention, gate, FFN), the fine-grained
+distribution refinement (FDR) heads and the query-based mask head.
+
+Behaviour and parameter names after the reference's src/d_fine/arch/dfine_decoder.py;
+what differs is how it runs on the device: the deformable gather is the HIP kernel behind
+``ops.deformable_attention_core`` on the channel-last memory (no per-level permute/copy, no
+grid_sample), anchors / W(n) / attention masks are cached on the device instead of being
+rebuilt on the host every forward, and the denoising group is built densely from a padded
+TargetBatch (no ``nonzero`` / per-image Python loop).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .configs import ModelSpec
+from .layers import MLP, ConvNorm, PackedSelfAttention, bias_for_prior
+from .targets import TargetBatch
+
+
+def inverse_sigmoid(x, eps=1e-5):
+    x = x.clamp(0.0, 1.0)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def weighting_function(reg_max, up, reg_scale):
+    """W(n): reg_max+1 non-uniform bin positions (arch/utils.py:145-188), fp32 on up's device."""
+    up0 = up.detach().float().reshape(-1)[0].abs()
+    ub1 = up0 * reg_scale.detach().reshape(-1)[0].abs()
+    ub2 = ub1 * 2
+    step = (ub1 + 1) ** (2 / (reg_max - 2))
+    left = [-(step**i) + 1 for i in range(reg_max // 2 - 1, 0, -1)]
+    right = [step**i - 1 for i in range(1, reg_max // 2)]
+    return torch.stack([-ub2] + left + [torch.zeros_like(ub1)] + right + [ub2]).float()
+
+
+def distance2bbox(points, distance, reg_scale):
+    """Edge distances (in units of the reference box / reg_scale) -> cxcywh (arch/utils.py:119-142)."""
+    rs = float(reg_scale)
+    half = 0.5 * rs
+    wq, hq = points[..., 2] / rs, points[..., 3] / rs
+    x1 = points[..., 0] - (half + distance[..., 0]) * wq
+    y1 = points[..., 1] - (half + distance[..., 1]) * hq
+    x2 = points[..., 0] + (half + distance[..., 2]) * wq
+    y2 = points[..., 1] + (half + distance[..., 3]) * hq
+    return torch.stack([(x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1], -1)
+
+
+class MSDeformableAttention(nn.Module):
+    """Offsets and weights from the query, locations around the 4-d reference box
+    (dfine_decoder.py:148-166), then the HIP gather. No value/output projection."""
+
+    def __init__(self, dim, n_head, num_points):
+        super().__init__()
+        self.n_head, self.num_points = n_head, list(num_points)
+        P = sum(num_points)
+        self.sampling_offsets = nn.Linear(dim, n_head * P * 2)
+        self.attention_weights = nn.Linear(dim, n_head * P)
+        self.register_buffer("num_points_scale", torch.tensor([1.0 / n for n in num_points for _ in range(n)]))
+        self._reset()
+
+    def _reset(self):  # reference init :100-117
+        nn.init.zeros_(self.sampling_offsets.weight)
+        theta = torch.arange(self.n_head, dtype=torch.float32) * (2.0 * math.pi / self.n_head)
+        grid = torch.stack([theta.cos(), theta.sin()], -1)
+        grid = grid / grid.abs().max(-1, keepdim=True).values
+        grid = grid.view(self.n_head, 1, 2).repeat(1, sum(self.num_points), 1)
+        grid = grid * torch.cat([torch.arange(1, n + 1) for n in self.num_points]).view(1, -1, 1)
+        with torch.no_grad():
+            self.sampling_offsets.bias.copy_(grid.flatten())
+        nn.init.zeros_(self.attention_weights.weight)
+        nn.init.zeros_(self.attention_weights.bias)
+
+    def forward(self, query, ref_boxes, value, spatial_shapes):
+        """query [B,Lq,D]; ref_boxes [B,Lq,4] cxcywh; value [B,S,nH,c] channel-last memory."""
+        B, Lq, _ = query.shape
+        nH, P = self.n_head, sum(self.num_points)
+        offsets = self.sampling_offsets(query).float().view(B, Lq, nH, P, 2)
+        weights = torch.softmax(self.attention_weights(query).float().view(B, Lq, nH, P), dim=-1)
+        ref = ref_boxes.float()[:, :, None, None, :]
+        loc = ref[..., :2] + offsets * (self.num_points_scale.view(P, 1) * 0.5) * ref[..., 2:]
+        return ops.deformable_attention_core(value, spatial_shapes, loc, weights, self.num_points)
+
+
+class Gate(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.gate = nn.Linear(2 * dim, 2 * dim)
+        nn.init.constant_(self.gate.bias, bias_for_prior(0.5))
+        nn.init.zeros_(self.gate.weight)
+        self.norm = nn.LayerNorm(dim)
+
+    def forward(self, a, b):
+        g1, g2 = torch.sigmoid(self.gate(torch.cat([a, b], -1))).chunk(2, -1)
+        return self.norm(g1 * a + g2 * b)
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, dim, n_head, ffn, num_points):
+        super().__init__()
+        self.self_attn = PackedSelfAttention(dim, n_head)
+        self.norm1 = nn.LayerNorm(dim)
+        self.cross_attn = MSDeformableAttention(dim, n_head, num_points)
+        self.gateway = Gate(dim)
+        self.linear1 = nn.Linear(dim, ffn)
+        self.linear2 = nn.Linear(ffn, dim)
+        self.norm3 = nn.LayerNorm(dim)
+        nn.init.xavier_uniform_(self.linear1.weight)
+        nn.init.xavier_uniform_(self.linear2.weight)
+
+    def forward(self, tgt, ref_boxes, value, spatial_shapes, blocked, pos):
+        tgt = self.norm1(tgt + self.self_attn(tgt + pos, tgt, blocked))
+        cross = self.cross_attn(tgt + pos, ref_boxes, value, spatial_shapes).to(tgt.dtype)
+        tgt = self.gateway(tgt, cross)
+        ffn = self.linear2(F.relu(self.linear1(tgt)))
+        return self.norm3((tgt + ffn).clamp(-65504, 65504))
+
+
+class LQE(nn.Module):
+    """Location-quality estimate added to every class logit (:298-313)."""
+
+    def __init__(self, k, hidden, reg_max):
+        super().__init__()
+        self.k, self.reg_max = k, reg_max
+        self.reg_conf = MLP(4 * (k + 1), hidden, 1, 2)
+        nn.init.zeros_(self.reg_conf.layers[-1].weight)
+        nn.init.zeros_(self.reg_conf.layers[-1].bias)
+
+    def forward(self, scores, corners):
+        B, L, _ = corners.shape
+        prob = torch.softmax(corners.float().view(B, L, 4, self.reg_max + 1), dim=-1)
+        top = prob.topk(self.k, dim=-1).values
+        stat = torch.cat([top, top.mean(-1, keepdim=True)], -1).view(B, L, -1)
+        return scores + self.reg_conf(stat.to(scores.dtype))
+
+
+class _DecoderStack(nn.Module):  # key paths ``decoder.decoder.layers.{i}`` / ``.lqe_layers.{i}``
+    def __init__(self, spec: ModelSpec, up, reg_scale):
+        super().__init__()
+        self.layers = nn.ModuleList(
+            DecoderLayer(spec.hidden, spec.num_heads, spec.dec_ffn, spec.num_points) for _ in range(spec.num_layers))
+        self.lqe_layers = nn.ModuleList(LQE(4, 64, spec.reg_max) for _ in range(spec.num_layers))
+        # the reference registers the SAME two Parameters here and on the parent (:400,597-598),
+        # so both ``decoder.up`` and ``decoder.decoder.up`` appear in its state_dict
+        self.up, self.reg_scale = up, reg_scale
+
+
+class MaskPixelDecoder(nn.Module):
+    """FPN maps -> 1x1+BN each, bilinear-summed at stride 8, + 1x1+BN of the PAN stride-8 memory,
+    then 2x2 stride-2 transposed conv + BN + ReLU: mask features at stride 4 (:316-376)."""
+
+    def __init__(self, in_chs, out_ch):
+        super().__init__()
+        self.lateral = nn.ModuleList(nn.Conv2d(c, out_ch, 1, bias=False) for c in in_chs)
+        self.bn = nn.ModuleList(nn.BatchNorm2d(out_ch) for _ in in_chs)
+        self.enc_proj = nn.Conv2d(in_chs[0], out_ch, 1, bias=False)
+        self.enc_bn = nn.BatchNorm2d(out_ch)
+        self.upconv = nn.ConvTranspose2d(out_ch, out_ch, 2, stride=2, bias=False)
+        self.bn1 = nn.BatchNorm2d(out_ch)
+
+    def forward(self, feats, enc_s8):
+        x = self.bn[0](self.lateral[0](feats[0]))
+        size = x.shape[-2:]
+        for i in range(1, len(feats)):
+            x = x + F.interpolate(self.bn[i](self.lateral[i](feats[i])), size=size, mode="bilinear", align_corners=False)
+        x = x + self.enc_bn(self.enc_proj(enc_s8))  # same size: the reference's bilinear resize is the identity
+        return F.relu(self.bn1(self.upconv(x)))
+
+
+class DFINETransformer(nn.Module):
+    def __init__(self, spec: ModelSpec, num_classes=80, eval_spatial_size=None, enable_mask_head=False):
+        super().__init__()
+        self.spec, self.num_classes = spec, num_classes
+        self.enable_mask_head = enable_mask_head
+        hid = spec.hidden
+        if spec.enc_hidden != hid:  # x: 384 -> 256 projection; Identity otherwise (:745-765)
+            self.input_proj = nn.ModuleList(ConvNorm(spec.enc_hidden, hid, 1) for _ in range(spec.num_levels))
+            for m in self.input_proj:
+                nn.init.xavier_uniform_(m.conv.weight)
+        else:
+            self.input_proj = nn.ModuleList(nn.Identity() for _ in range(spec.num_levels))
+        self.up = nn.Parameter(torch.tensor([0.5]), requires_grad=False)
+        self.reg_scale = nn.Parameter(torch.tensor([spec.reg_scale]), requires_grad=False)  # int64, as shipped
+        self.decoder = _DecoderStack(spec, self.up, self.reg_scale)
+        self.denoising_class_embed = nn.Embedding(num_classes + 1, hid, padding_idx=num_classes)
+        nn.init.normal_(self.denoising_class_embed.weight[:-1])
+        if enable_mask_head:
+            self.pixel_decoder = MaskPixelDecoder([spec.enc_hidden] * spec.num_levels, spec.mask_dim)
+            self.mask_head = MLP(hid, hid, spec.mask_dim, 3)
+        self.query_pos_head = MLP(4, 2 * hid, hid, 2)
+        self.enc_output = nn.Sequential()
+        self.enc_output.add_module("proj", nn.Linear(hid, hid))
+        self.enc_output.add_module("norm", nn.LayerNorm(hid))
+        self.enc_score_head = nn.Linear(hid, num_classes)
+        self.enc_bbox_head = MLP(hid, hid, 4, 3)
+        self.dec_score_head = nn.ModuleList(nn.Linear(hid, num_classes) for _ in range(spec.num_layers))
+        self.pre_bbox_head = MLP(hid, hid, 4, 3)
+        self.dec_bbox_head = nn.ModuleList(MLP(hid, hid, 4 * (spec.reg_max + 1), 3) for _ in range(spec.num_layers))
+        if eval_spatial_size:  # buffers in the checkpoint layout (:700-706)
+            h, w = eval_spatial_size
+            anchors, valid = self.generate_anchors([(int(h / s), int(w / s)) for s in spec.strides])
+            self.register_buffer("anchors", anchors)
+            self.register_buffer("valid_mask", valid)
+        self._reset()
+        self._cache = {}
+
+    def _reset(self):  # reference init :720-743
+        prior = bias_for_prior(0.01)
+        nn.init.constant_(self.enc_score_head.bias, prior)
+        for head in (self.enc_bbox_head, self.pre_bbox_head, *self.dec_bbox_head):
+            nn.init.zeros_(head.layers[-1].weight)
+            nn.init.zeros_(head.layers[-1].bias)
+        for cls in self.dec_score_head:
+            nn.init.constant_(cls.bias, prior)
+        nn.init.xavier_uniform_(self.enc_output.proj.weight)
+        nn.init.xavier_uniform_(self.query_pos_head.layers[0].weight)
+        nn.init.xavier_uniform_(self.query_pos_head.layers[1].weight)
+
+    # ---------------------------------------------------------------- cached device constants
+    def generate_anchors(self, spatial_shapes, device="cpu"):
+        """(:815-838) logit-space anchors [1,S,4] (inf where invalid) and valid mask [1,S,1]."""
+        spec, out = self.spec, []
+        for lvl, (h, w) in enumerate(spatial_shapes):
+            gy, gx = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
+            xy = (torch.stack([gx, gy], -1).float() + 0.5) / torch.tensor([w, h], dtype=torch.float32, device=device)
+            wh = torch.full_like(xy, spec.anchor_grid * (2.0**lvl))
+            out.append(torch.cat([xy, wh], -1).view(1, h * w, 4))
+        anchors = torch.cat(out, 1)
+        valid = ((anchors > spec.anchor_eps) & (anchors < 1 - spec.anchor_eps)).all(-1, keepdim=True)
+        anchors = torch.log(anchors / (1 - anchors))
+        return torch.where(valid, anchors, torch.inf), valid
+
+    def _cached(self, key, make):
+        if key not in self._cache:
+            self._cache[key] = make()
+        return self._cache[key]
+
+    def _dn_attention_mask(self, max_gt, groups, device):
+        """bool [Nd+Q, Nd+Q], True = blocked (arch/utils.py:437-455)."""
+        def make():
+            Q, Nd = self.spec.num_queries, 2 * max_gt * groups
+            m = torch.zeros(Nd + Q, Nd + Q, dtype=torch.bool)
+            m[Nd:, :Nd] = True
+            for g in range(groups):
+                lo, hi = 2 * max_gt * g, 2 * max_gt * (g + 1)
+                m[lo:hi, hi:Nd] = True
+                m[lo:hi, :lo] = True
+            return m.to(device)
+        return self._cached(("dn_mask", max_gt, groups, str(device)), make)
+
+    # ---------------------------------------------------------------- denoising queries
+    def denoising_group(self, tb: TargetBatch, noise=None):
+        """Contrastive denoising queries (arch/utils.py:357-467, invoked with box_noise_scale=1.0
+        at dfine_decoder.py:949-959), dense over the padded TargetBatch. ``noise`` (dict with
+        flip_u [B,N], new_label [B,N], sign01 [B,N,4], part_u [B,N,4]) can be injected for parity;
+        otherwise it is drawn on the device. Returns (content, bbox_unact, blocked, dn_meta)."""
+        spec, C = self.spec, self.num_classes
+        if tb.total == 0 or spec.num_denoising <= 0:
+            return None, None, None, {"dn_num_group": 0, "dn_num_split": [0, spec.num_queries], "dn_assign": None}
+        G = max(tb.num_gts)
+        groups = max(1, spec.num_denoising // G)
+        B, N, dev = tb.labels.shape[0], 2 * G * groups, tb.labels.device
+        cls = tb.labels[:, :G].repeat(1, 2 * groups)
+        box = tb.boxes[:, :G].repeat(1, 2 * groups, 1)
+        pad = tb.valid[:, :G].repeat(1, 2 * groups)
+        slot = torch.arange(N, device=dev) % (2 * G)
+        negative = (slot >= G).view(1, N, 1).float()
+        if noise is None:
+            noise = dict(flip_u=torch.rand(B, N, device=dev), new_label=torch.randint(0, C, (B, N), device=dev),
+                         sign01=torch.randint(0, 2, (B, N, 4), device=dev).float(), part_u=torch.rand(B, N, 4, device=dev))
+        flip = (noise["flip_u"] < spec.label_noise_ratio * 0.5) & pad
+        cls = torch.where(flip, noise["new_label"].long(), cls)
+        half_wh = box[..., 2:].clamp(min=0) * 0.5
+        xyxy = torch.cat([box[..., :2] - half_wh, box[..., :2] + half_wh], -1)
+        reach = (box[..., 2:] * 0.5).repeat(1, 1, 2)
+        part = noise["part_u"] + negative  # negatives jitter by 1..2 box halves, positives by 0..1
+        xyxy = (xyxy + (noise["sign01"] * 2.0 - 1.0) * part * reach).clamp(0.0, 1.0)
+        box = torch.cat([(xyxy[..., :2] + xyxy[..., 2:]) / 2, xyxy[..., 2:] - xyxy[..., :2]], -1).abs()
+        content = self.denoising_class_embed(cls)
+        assign = torch.where((slot < G)[None, :] & pad, slot[None, :].expand(B, N), -1)  # GT index of positive slots
+        meta = {"dn_num_group": groups, "dn_num_split": [N, spec.num_queries], "dn_assign": assign}
+        return content, inverse_sigmoid(box), self._dn_attention_mask(G, groups, dev), meta
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, feats, inner_feats, targets=None, inject=None):
+        spec, inject = self.spec, inject or {}
+        training = self.training
+        Q, L = spec.num_queries, spec.num_layers
+        proj = [p(f) for p, f in zip(self.input_proj, feats)]
+        spatial_shapes = [tuple(f.shape[2:]) for f in proj]
+        # channel-last maps flatten to [B, HW, C] views; the concat is the decoder memory AND the
+        # deformable-attention value (value_op ignores value_proj, :416-426)
+        memory = torch.cat([f.permute(0, 2, 3, 1).flatten(1, 2) for f in proj], 1)
+        B, S, hid = memory.shape
+        dev = memory.device
+
+        tb = None
+        if targets is not None:
+            tb = TargetBatch.from_list(targets, self.num_classes, dev)
+        do_masks = self.enable_mask_head and (tb is None or tb.masks is not None)
+
+        dn_content = dn_bbox = blocked = dn_meta = None
+        if training:
+            dn_content, dn_bbox, blocked, dn_meta = self.denoising_group(tb, inject.get("cdn_noise"))
+
+        # ---- query selection (:840-922)
+        key = ("anchors", tuple(spatial_shapes), str(dev))
+        anchors, valid = self._cached(key, lambda: self.generate_anchors(spatial_shapes, dev))
+        enc_mem = self.enc_output(memory * valid.to(memory.dtype))
+        enc_logits = self.enc_score_head(enc_mem)
+        topk_ind = inject.get("topk_ind")
+        if topk_ind is None:
+            topk_ind = torch.topk(enc_logits.max(-1).values, Q, dim=-1).indices
+        pick = lambda t: t.gather(1, topk_ind.unsqueeze(-1).expand(-1, -1, t.shape[-1]))
+        topk_mem, topk_logits = pick(enc_mem), pick(enc_logits)
+        enc_bbox_unact = self.enc_bbox_head(topk_mem).float() + pick(anchors.expand(B, -1, -1))
+        content, ref_unact = topk_mem.detach(), enc_bbox_unact.detach()
+        if dn_bbox is not None:
+            ref_unact = torch.cat([dn_bbox, ref_unact], 1)
+            content = torch.cat([dn_content.to(content.dtype), content], 1)
+
+        # ---- decoder layers + FDR heads (:435-530)
+        value = memory.view(B, S, spec.num_heads, hid // spec.num_heads)
+        project = self._cached(("W", str(dev)), lambda: weighting_function(spec.reg_max, self.up, self.reg_scale).to(dev))
+        reg_scale = float(spec.reg_scale)
+        out, out_detach, corners_prev = content, 0, 0
+        ref_detach = torch.sigmoid(ref_unact)
+        boxes_l, logits_l, corners_l, hs = [], [], [], []
+        for i, layer in enumerate(self.decoder.layers):
+            pos = self.query_pos_head(ref_detach).clamp(-10, 10)
+            out = layer(out, ref_detach, value, spatial_shapes, blocked, pos)
+            hs.append(out)
+            if i == 0:
+                pre_boxes = torch.sigmoid(self.pre_bbox_head(out).float() + inverse_sigmoid(ref_detach))
+                pre_logits = self.dec_score_head[0](out)
+                ref_initial = pre_boxes.detach()
+            corners = self.dec_bbox_head[i](out + out_detach).float() + corners_prev
+            prob = torch.softmax(corners.view(B, -1, 4, spec.reg_max + 1), dim=-1)
+            box = distance2bbox(ref_initial, prob @ project, reg_scale)
+            if training or i == L - 1:
+                logits_l.append(self.decoder.lqe_layers[i](self.dec_score_head[i](out), corners))
+                boxes_l.append(box)
+                corners_l.append(corners)
+            corners_prev, ref_detach, out_detach = corners, box.detach(), out.detach()
+
+        # ---- mask branch (:999-1022)
+        if do_masks:
+            h8, w8 = spatial_shapes[0]
+            mem0 = memory[:, : h8 * w8].transpose(1, 2).reshape(B, hid, h8, w8)
+            mask_feat = self.pixel_decoder(inner_feats, mem0)
+            mask_of = lambda h: torch.einsum("bqc,bchw->bqhw", self.mask_head(h), mask_feat)
+
+        if not training:
+            res = {"pred_logits": logits_l[-1], "pred_boxes": boxes_l[-1]}
+            if do_masks:
+                res["pred_masks"] = torch.sigmoid(mask_of(hs[-1]))
+            return res
+
+        Nd = dn_meta["dn_num_split"][0]
+        dn_part = lambda t: t[:, :Nd]
+        reg_part = lambda t: t[:, Nd:]
+
+        def head(part, i, teacher, masks=None):
+            d = {"pred_logits": part(logits_l[i]), "pred_boxes": part(boxes_l[i]), "pred_corners": part(corners_l[i]),
+                 "ref_points": part(ref_initial), "teacher_corners": part(corners_l[-1]) if teacher else None,
+                 "teacher_logits": part(logits_l[-1]) if teacher else None}
+            if teacher and i == L - 1:
+                d["self_distilled"] = True  # teacher == student: the reference finds out with torch.equal (a sync)
+            if masks is not None:
+                d["pred_masks"] = masks[i]
+            return d
+
+        reg_masks = [mask_of(reg_part(h)) for h in hs] if do_masks else None
+        res = {k: v for k, v in head(reg_part, L - 1, False).items() if v is not None}
+        res.update(up=self.up, reg_scale=self.reg_scale)
+        res["fdr"] = {"W": project, "reg_scale": reg_scale}  # host-side copies so the criterion need not read the Parameters back
+        if do_masks:
+            res["pred_masks"] = reg_masks[-1]
+        res["aux_outputs"] = [head(reg_part, i, True, reg_masks) for i in range(L - 1)]
+        res["enc_aux_outputs"] = [{"pred_logits": topk_logits, "pred_boxes": torch.sigmoid(enc_bbox_unact)}]
+        res["pre_outputs"] = {"pred_logits": reg_part(pre_logits), "pred_boxes": reg_part(pre_boxes)}
+        res["enc_meta"] = {"class_agnostic": False}
+        dn_masks = [mask_of(dn_part(h)) for h in hs] if do_masks else None
+        # detection: every layer's dn head; with masks the reference's zip truncates to L-1 layers and
+        # carries the last layer's dn masks separately (:1059-1070)
+        n_dn = L - 1 if do_masks else L
+        res["dn_outputs"] = [head(dn_part, i, True, dn_masks) for i in range(n_dn)]
+        if dn_masks is not None:
+            res["dn_pred_masks"] = dn_masks[-1]
+        res["dn_pre_outputs"] = {"pred_logits": dn_part(pre_logits), "pred_boxes": dn_part(pre_boxes)}
+        res["dn_meta"] = dn_meta
+        res["targets"] = tb  # the packed batch, so the criterion does not pack it again
+        return res

@@ -1,0 +1,137 @@
+"""Hybrid encoder: 1x1 projections, one transformer layer (AIFI) on the coarsest map, then a
+top-down FPN and bottom-up PAN built from RepNCSPELAN4 blocks. Behaviour and parameter
+names after the reference's src/d_fine/arch/hybrid_encoder.py (forward :443-486).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .configs import ModelSpec
+from .layers import ConvNorm, PackedSelfAttention
+
+
+class RepVgg(nn.Module):
+    """silu(conv3x3+norm + conv1x1+norm), training form of VGGBlock (:106-121)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv1 = ConvNorm(c, c, 3)
+        self.conv2 = ConvNorm(c, c, 1)
+
+    def forward(self, x):
+        return F.silu(self.conv1(x) + self.conv2(x))
+
+
+class CSP(nn.Module):
+    """Two 1x1 branches, one through n RepVgg blocks, summed (CSPLayer :209-239 with
+    expansion 1.0, hence no conv3)."""
+
+    def __init__(self, c_in, c_out, n):
+        super().__init__()
+        self.conv1 = ConvNorm(c_in, c_out, 1, act="silu")
+        self.conv2 = ConvNorm(c_in, c_out, 1, act="silu")
+        self.bottlenecks = nn.Sequential(*[RepVgg(c_out) for _ in range(n)])
+
+    def forward(self, x):
+        return self.bottlenecks(self.conv1(x)) + self.conv2(x)
+
+
+class RepNCSPELAN4(nn.Module):
+    def __init__(self, c_in, c_out, c_mid, c_branch, n):
+        super().__init__()
+        self.cv1 = ConvNorm(c_in, c_mid, 1, act="silu")
+        self.cv2 = nn.Sequential(CSP(c_mid // 2, c_branch, n), ConvNorm(c_branch, c_branch, 3, act="silu"))
+        self.cv3 = nn.Sequential(CSP(c_branch, c_branch, n), ConvNorm(c_branch, c_branch, 3, act="silu"))
+        self.cv4 = ConvNorm(c_mid + 2 * c_branch, c_out, 1, act="silu")
+
+    def forward(self, x):
+        y = self.cv1(x)
+        a, b = y.chunk(2, dim=1)
+        c = self.cv2(b)
+        d = self.cv3(c)
+        return self.cv4(torch.cat([a, b, c, d], 1))
+
+
+class SCDown(nn.Module):
+    def __init__(self, c, k, s):
+        super().__init__()
+        self.cv1 = ConvNorm(c, c, 1)
+        self.cv2 = ConvNorm(c, c, k, stride=s, groups=c)
+
+    def forward(self, x):
+        return self.cv2(self.cv1(x))
+
+
+class EncoderLayer(nn.Module):
+    """Post-norm transformer layer, GELU FFN, dropout 0 (:243-290)."""
+
+    def __init__(self, dim, n_head, ffn):
+        super().__init__()
+        self.self_attn = PackedSelfAttention(dim, n_head)
+        self.linear1 = nn.Linear(dim, ffn)
+        self.linear2 = nn.Linear(ffn, dim)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+
+    def forward(self, x, pos):
+        x = self.norm1(x + self.self_attn(x + pos, x))
+        return self.norm2(x + self.linear2(F.gelu(self.linear1(x))))
+
+
+class _LayerStack(nn.Module):  # gives the reference's key path ``encoder.0.layers.0``
+    def __init__(self, layer):
+        super().__init__()
+        self.layers = nn.ModuleList([layer])
+
+
+def sincos_position_embedding(w, h, dim, temperature=10000.0, device=None):
+    """[1, w*h, dim] table, reference semantics (:425-441): called with (w, h), built from
+    meshgrid(arange(w), arange(h), indexing="ij"), yet consumed by row-major (y*W+x) tokens --
+    so for token t the first half encodes t // h and the second t % h. Kept as is."""
+    gw, gh = torch.meshgrid(torch.arange(int(w), dtype=torch.float32, device=device),
+                            torch.arange(int(h), dtype=torch.float32, device=device), indexing="ij")
+    omega = 1.0 / (temperature ** (torch.arange(dim // 4, dtype=torch.float32, device=device) / (dim // 4)))
+    ow, oh = gw.flatten()[:, None] * omega[None], gh.flatten()[:, None] * omega[None]
+    return torch.cat([ow.sin(), ow.cos(), oh.sin(), oh.cos()], 1)[None]
+
+
+class HybridEncoder(nn.Module):
+    def __init__(self, spec: ModelSpec):
+        super().__init__()
+        hid, L = spec.enc_hidden, spec.num_levels
+        self.hidden = hid
+        self.input_proj = nn.ModuleList(ConvNorm(c, hid, 1) for c in spec.in_channels)
+        self.encoder = nn.ModuleList([_LayerStack(EncoderLayer(hid, spec.num_heads, spec.enc_ffn))])
+        elan = lambda: RepNCSPELAN4(hid * 2, hid, hid * 2, spec.csp_c4, spec.csp_blocks)
+        self.lateral_convs = nn.ModuleList(ConvNorm(hid, hid, 1) for _ in range(L - 1))
+        self.fpn_blocks = nn.ModuleList(elan() for _ in range(L - 1))
+        self.downsample_convs = nn.ModuleList(nn.Sequential(SCDown(hid, 3, 2)) for _ in range(L - 1))
+        self.pan_blocks = nn.ModuleList(elan() for _ in range(L - 1))
+        self._pos_cache = {}
+
+    def _pos(self, w, h, device):
+        key = (w, h, str(device))
+        if key not in self._pos_cache:  # the reference rebuilds this on the CPU every forward
+            self._pos_cache[key] = sincos_position_embedding(w, h, self.hidden, device=device)
+        return self._pos_cache[key]
+
+    def forward(self, feats):
+        """feats: backbone maps, fine to coarse -> (outs, inner_outs), both fine to coarse."""
+        proj = [p(f) for p, f in zip(self.input_proj, feats)]
+        x = proj[-1]
+        B, C, h, w = x.shape
+        tokens = x.flatten(2).transpose(1, 2)  # a view for channel-last maps
+        tokens = self.encoder[0].layers[0](tokens, self._pos(w, h, x.device).to(tokens.dtype))
+        proj[-1] = tokens.transpose(1, 2).reshape(B, C, h, w).contiguous(memory_format=torch.channels_last)
+
+        inner = [proj[-1]]
+        for lvl in range(len(proj) - 1, 0, -1):
+            j = len(proj) - 1 - lvl
+            inner[0] = self.lateral_convs[j](inner[0])
+            up = F.interpolate(inner[0], scale_factor=2.0, mode="nearest")
+            inner.insert(0, self.fpn_blocks[j](torch.cat([up, proj[lvl - 1]], 1)))
+        outs = [inner[0]]
+        for lvl in range(len(proj) - 1):
+            down = self.downsample_convs[lvl](outs[-1])
+            outs.append(self.pan_blocks[lvl](torch.cat([down, inner[lvl + 1]], 1)))
+        return outs, inner

@@ -1,0 +1,120 @@
+"""Building blocks shared by backbone / encoder / decoder. Parameter and buffer names (and
+therefore ``state_dict`` keys) follow the reference so checkpoints are interchangeable
+(SURVEY.md A.10); tensors are channel-last (NHWC memory) end to end.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """Affine + statistics as fixed buffers (reference src/d_fine/arch/common.py:29-67; eps inside
+    the rsqrt). Used for every backbone norm of the l/x sizes."""
+
+    def __init__(self, n, eps=1e-5):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+        self.eps = eps
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        state_dict.pop(prefix + "num_batches_tracked", None)  # plain-BN checkpoints load too
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def forward(self, x):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        shift = self.bias - self.running_mean * scale
+        return x * scale.view(1, -1, 1, 1).to(x.dtype) + shift.view(1, -1, 1, 1).to(x.dtype)
+
+
+class LearnableAffine(nn.Module):
+    """Scalar scale*x + bias after the activation (hgnetv2.py:25-32)."""
+
+    def __init__(self):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor([1.0]))
+        self.bias = nn.Parameter(torch.tensor([0.0]))
+
+    def forward(self, x):
+        return torch.addcmul(self.bias.to(x.dtype), x, self.scale.to(x.dtype))
+
+
+_ACTS = {None: None, "relu": F.relu, "silu": F.silu}
+
+
+class ConvNorm(nn.Module):
+    """conv (no bias) -> batch norm -> activation -> optional learnable affine.
+
+    One class for the reference's ConvBNAct (norm attribute ``bn``, hgnetv2.py:35-80) and
+    ConvNormLayer / ConvNormLayer_fuse (attribute ``norm``, hybrid_encoder.py:21-93)."""
+
+    def __init__(self, c_in, c_out, k, stride=1, groups=1, act=None, lab=False, norm_name="norm",
+                 frozen_norm=False, padding=None):
+        super().__init__()
+        self.conv = nn.Conv2d(c_in, c_out, k, stride, (k - 1) // 2 if padding is None else padding,
+                              groups=groups, bias=False)
+        self.norm_name = norm_name
+        setattr(self, norm_name, FrozenBatchNorm2d(c_out) if frozen_norm else nn.BatchNorm2d(c_out))
+        self.act = _ACTS[act]
+        if lab and act is not None:
+            self.lab = LearnableAffine()
+
+    def forward(self, x):
+        x = getattr(self, self.norm_name)(self.conv(x))
+        if self.act is not None:
+            x = self.act(x)
+        if hasattr(self, "lab"):
+            x = self.lab(x)
+        return x
+
+
+class MLP(nn.Module):
+    """Linear stack with ReLU in between (dfine_decoder.py:33-46); keys ``layers.{i}``."""
+
+    def __init__(self, d_in, d_hidden, d_out, n_layers):
+        super().__init__()
+        dims = [d_in] + [d_hidden] * (n_layers - 1) + [d_out]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i + 1 < len(self.layers):
+                x = F.relu(x)
+        return x
+
+
+class PackedSelfAttention(nn.Module):
+    """Self-attention with nn.MultiheadAttention's parameter layout (``in_proj_weight``
+    [3D, D], ``in_proj_bias``, ``out_proj.{weight,bias}``) where queries and keys share one
+    input and values another: q = k = x + pos, v = x (hybrid_encoder.py:274-277,
+    dfine_decoder.py:236-239). The QK projection is a single GEMM."""
+
+    def __init__(self, dim, n_head):
+        super().__init__()
+        self.dim, self.n_head = dim, n_head
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * dim, dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * dim))
+        self.out_proj = nn.Linear(dim, dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+    def forward(self, qk_in, v_in, blocked=None):
+        """qk_in, v_in: [B, L, D]; blocked: optional bool [L, L], True = may NOT attend."""
+        B, L, D = qk_in.shape
+        H, dh = self.n_head, D // self.n_head
+        qk = F.linear(qk_in, self.in_proj_weight[: 2 * D], self.in_proj_bias[: 2 * D])
+        v = F.linear(v_in, self.in_proj_weight[2 * D :], self.in_proj_bias[2 * D :])
+        q, k = qk.view(B, L, 2, H, dh).permute(2, 0, 3, 1, 4)
+        v = v.view(B, L, H, dh).transpose(1, 2)
+        allowed = None if blocked is None else ~blocked
+        out = F.scaled_dot_product_attention(q, k, v, attn_mask=allowed)
+        return self.out_proj(out.transpose(1, 2).reshape(B, L, D))
+
+
+def bias_for_prior(p):
+    return -math.log((1 - p) / p)

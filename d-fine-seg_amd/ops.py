@@ -88,3 +88,52 @@ def value_from_reference_layout(value_levels) -> torch.Tensor:
     """Reference ``value_op`` output (tuple of ``(B, n_head, c, H_l*W_l)``,
     dfine_decoder.py:416-426) -> channel-last ``[B, S, n_head, c]``."""
     return torch.cat(list(value_levels), dim=-1).permute(0, 3, 1, 2).contiguous()
+
+
+@torch.no_grad()
+def hungarian_match(pred_logits, pred_boxes, tgt_labels, tgt_boxes, num_gt, alpha=0.25, gamma=2.0,
+                    cost_class=2.0, cost_bbox=5.0, cost_giou=2.0):
+    """MI355X replacement for ``HungarianMatcher.forward`` (reference src/d_fine/matcher.py:52-130)
+    for ALL heads of a step at once, with nothing copied to the host.
+
+    pred_logits [H, B, Q, C], pred_boxes [H, B, Q, 4] (cxcywh); tgt_labels int64 [B, G],
+    tgt_boxes f32 [B, G, 4] padded; num_gt int32 [B] on the device.
+    Returns (gt_of_query int32 [H, B, Q], query_of_gt int32 [H, B, G]); -1 = unmatched / padding.
+    The reference's per-image (query_idx, gt_idx) lists are ``(query_of_gt[h, b, :n], arange(n))``.
+    """
+    _lib.require_gpu(pred_logits, pred_boxes, tgt_labels, tgt_boxes, num_gt)
+    lib = _lib.load()
+    H, B, Q, C = pred_logits.shape
+    G = tgt_labels.shape[1]
+    logits = pred_logits.float().contiguous()
+    boxes = pred_boxes.float().contiguous()
+    tgt_labels = tgt_labels.to(torch.int64).contiguous()
+    tgt_boxes = tgt_boxes.float().contiguous()
+    num_gt = num_gt.to(torch.int32).contiguous()
+    dev = logits.device
+    cost = torch.empty(H * B, G, Q, dtype=torch.float32, device=dev)
+    query_of_gt = torch.empty(H, B, G, dtype=torch.int32, device=dev)
+    gt_of_query = torch.empty(H, B, Q, dtype=torch.int32, device=dev)
+    st = _lib.stream_ptr()
+    rc = lib.dfine_match_cost(_lib.ptr(logits), _lib.ptr(boxes), _lib.ptr(tgt_labels), _lib.ptr(tgt_boxes),
+                              _lib.ptr(num_gt), _lib.ptr(cost), H * B, B, Q, C, G, alpha, gamma,
+                              cost_class, cost_bbox, cost_giou, st)
+    _lib.check(rc, "dfine_match_cost")
+    rc = lib.dfine_lsap(_lib.ptr(cost), _lib.ptr(num_gt), _lib.ptr(query_of_gt), _lib.ptr(gt_of_query),
+                        H * B, B, G, Q, st)
+    _lib.check(rc, "dfine_lsap")
+    return gt_of_query, query_of_gt
+
+
+@torch.no_grad()
+def go_union(gt_of_query):
+    """Dense form of ``DFINECriterion._get_go_indices`` (dfine_criterion.py:371-392):
+    gt_of_query int32 [H, B, Q] -> go int32 [B, Q] (most frequent GT per query, -1 = none)."""
+    _lib.require_gpu(gt_of_query)
+    lib = _lib.load()
+    H, B, Q = gt_of_query.shape
+    gt_of_query = gt_of_query.contiguous()
+    go = torch.empty(B, Q, dtype=torch.int32, device=gt_of_query.device)
+    rc = lib.dfine_go_union(_lib.ptr(gt_of_query), _lib.ptr(go), H, B, Q, _lib.stream_ptr())
+    _lib.check(rc, "dfine_go_union")
+    return go

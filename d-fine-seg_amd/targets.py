@@ -1,0 +1,80 @@
+"""Padded, device-resident view of a batch's ground truth.
+
+The reference hands the model and the criterion a Python list of per-image dicts
+(src/dl/dataset.py:617-640) and re-reads it tensor by tensor, with ``.item()``/``nonzero``
+host syncs along the way. Here the list is packed ONCE per step into fixed-shape tensors
+(only the per-image counts stay on the host, where ``len()`` already knows them), so
+everything downstream is dense, mask-driven and free of host round-trips.
+"""
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class TargetBatch:
+    labels: torch.Tensor  # int64 [B, G]   padded with num_classes
+    boxes: torch.Tensor  # f32   [B, G, 4] cxcywh in [0,1], padded with 0
+    valid: torch.Tensor  # bool  [B, G]
+    num_gts: List[int]  # host
+    counts: torch.Tensor = None  # int32 [B] on the device (same numbers as num_gts)
+    masks: Optional[List[Optional[torch.Tensor]]] = None  # per image uint8 [n, H, W] (segment task)
+
+    @property
+    def max_gt(self):
+        return self.labels.shape[1]
+
+    @property
+    def total(self):
+        return sum(self.num_gts)
+
+    @staticmethod
+    def from_list(targets, num_classes, device):
+        """targets: list of {"labels" [n], "boxes" [n,4], optional "masks" [n,H,W]} (CPU or GPU)."""
+        if isinstance(targets, TargetBatch):
+            return targets
+        num_gts = [int(t["labels"].shape[0]) for t in targets]
+        B, G = len(targets), max(max(num_gts, default=0), 1)
+        labels = torch.full((B, G), num_classes, dtype=torch.int64)
+        boxes = torch.zeros(B, G, 4, dtype=torch.float32)
+        on_host = all(not t["labels"].is_cuda for t in targets)
+        if on_host:  # one pinned staging buffer, one H2D copy per tensor kind
+            for i, t in enumerate(targets):
+                n = num_gts[i]
+                if n:
+                    labels[i, :n] = t["labels"]
+                    boxes[i, :n] = t["boxes"]
+            if torch.device(device).type == "cuda":
+                labels, boxes = labels.pin_memory(), boxes.pin_memory()
+            labels = labels.to(device, non_blocking=True)
+            boxes = boxes.to(device, non_blocking=True)
+        else:
+            labels, boxes = labels.to(device), boxes.to(device)
+            for i, t in enumerate(targets):
+                n = num_gts[i]
+                if n:
+                    labels[i, :n] = t["labels"].to(device)
+                    boxes[i, :n] = t["boxes"].to(device)
+        counts = torch.tensor(num_gts, dtype=torch.int64)
+        valid = (torch.arange(G)[None, :] < counts[:, None]).to(device, non_blocking=True)
+        masks = None
+        if any(t.get("masks") is not None and t["masks"].numel() > 0 for t in targets):
+            masks = [t.get("masks") for t in targets]
+        return TargetBatch(labels, boxes, valid, num_gts, counts.to(torch.int32).to(device, non_blocking=True), masks)
+
+    def mask_targets(self, out_h, out_w, device):
+        """GT masks nearest-resized to the prediction size (dfine_criterion.py:239-270), padded to
+        [B, G, out_h, out_w] float32. Images without masks contribute zeros (and are excluded by
+        ``has_masks``)."""
+        B, G = self.labels.shape
+        out = torch.zeros(B, G, out_h, out_w, dtype=torch.float32, device=device)
+        has = torch.zeros(B, dtype=torch.bool)
+        for i, m in enumerate(self.masks or []):
+            if m is None or m.numel() == 0 or m.dim() != 3:
+                continue
+            m = m.to(device, non_blocking=True)
+            out[i, : m.shape[0]] = F.interpolate(m[None].float(), size=(out_h, out_w), mode="nearest")[0].clamp_(0, 1)
+            has[i] = True
+        return out, has.to(device)

@@ -80,6 +80,37 @@ int dfine_msda_bwd(const void* value, int value_dtype, const float* loc, const f
                    int B, int S, int Lq, int nH, int c, int n_levels, const int32_t* level_hw,
                    const int32_t* num_points, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Hungarian matching without leaving the device. Replaces HungarianMatcher.forward
+ * (src/d_fine/matcher.py:52-130): the cost matrix (:76-112), the device->host copy (:112) and
+ * the per-image scipy.optimize.linear_sum_assignment calls (:116), for N = heads*B problems in
+ * one launch each. Problem p uses image p % B.
+ *
+ *   logits      [N, Q, C]  f32     boxes     [N, Q, 4] f32 cxcywh
+ *   tgt_labels  [B, G]     int64   tgt_boxes [B, G, 4] f32   num_gt [B] int32 (rows >= num_gt ignored)
+ *   cost        [N, G, Q]  f32     workspace/output: cost[p][g][q], gt-major so one LSAP row is
+ *                                  contiguous over the queries; rows g >= num_gt are not written
+ * ------------------------------------------------------------------------------------- */
+int dfine_match_cost(const float* logits, const float* boxes, const int64_t* tgt_labels,
+                     const float* tgt_boxes, const int32_t* num_gt, float* cost, int N, int B,
+                     int Q, int C, int G, float alpha, float gamma, float w_class, float w_bbox,
+                     float w_giou, void* stream);
+
+/* Linear sum assignment of every problem's [num_gt x Q] cost block (double precision inside,
+ * same optimum AND same tie-breaking as scipy's rectangular_lsap). Needs num_gt <= Q.
+ *   query_of_gt [N, G] int32   query assigned to ground truth g (-1 for g >= num_gt)
+ *   gt_of_query [N, Q] int32   ground truth assigned to query q (-1 = unmatched)
+ */
+int dfine_lsap(const float* cost, const int32_t* num_gt, int32_t* query_of_gt,
+               int32_t* gt_of_query, int N, int B, int G, int Q, void* stream);
+
+/* Union of the H heads' matchings (DFINECriterion._get_go_indices,
+ * src/d_fine/dfine_criterion.py:371-392), dense: go[b][q] = ground truth most often matched to
+ * query q over the heads (ties -> smallest index), -1 if never matched.
+ *   gt_of_query [H, B, Q] int32   ->   go [B, Q] int32
+ */
+int dfine_go_union(const int32_t* gt_of_query, int32_t* go, int H, int B, int Q, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
