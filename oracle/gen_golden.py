@@ -111,6 +111,7 @@ MODEL_CASES = {
     "model_x640": ("x", 640, [2, 5], False),  # x architecture (frozen BN, 384->256 proj) at a small image
 }
 SEED_WEIGHTS_IMG, SEED_TARGETS, SEED_CDN = 1, 2, 123
+BF16_CALIBRATION = ("model_m640",)
 
 
 def gen_model(names=None):
@@ -178,6 +179,31 @@ def gen_model(names=None):
         for hname, d in heads.items():
             out[f"train.{hname}.pred_boxes"] = d["pred_boxes"]
             out[f"train.{hname}.pred_logits.sample"], out[f"train.{hname}.pred_logits.absmean"] = _sample(d["pred_logits"], 2048)
+
+        if fname in BF16_CALIBRATION:
+            # the reference's own bf16-autocast error (its AMP path, CPU flavour) on quantities that do
+            # not depend on query selection: calibrates the tolerance of the product's bf16 run
+            import copy
+
+            m16 = copy.deepcopy(model)
+            m16.load_state_dict(weights.fill_state_dict(model.state_dict()), strict=True)  # fresh BN stats
+            m16.train()
+            g16 = {}
+            hk = [m16.encoder.register_forward_hook(lambda m, i, o: g16.__setitem__("encoder", o)),
+                  m16.decoder.enc_score_head.register_forward_hook(lambda m, i, o: g16.__setitem__("enc_logits", o))]
+            torch.manual_seed(SEED_CDN)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                res16 = m16(x, targets=targets)
+            ref_configs.models[size]["DFINECriterion"]["losses"] = ["vfl", "boxes", "local"]
+            loss16 = build_loss(size, 80, 0.0, seg)(res16, targets)  # loss outside autocast, as train.py:548
+            out["bf16ref.loss.total"] = torch.stack([v.detach().float().reshape(()) for v in loss16.values()]).sum()
+            for h in hk:
+                h.remove()
+            for lvl, f in enumerate(g16["encoder"][0]):
+                out[f"bf16ref.encoder.outs.{lvl}.sample"], _ = _sample(f)
+            idx = out["topk_ind"].unsqueeze(-1).expand(-1, -1, 80)
+            out["bf16ref.enc0.pred_logits.sample"], _ = _sample(g16["enc_logits"].float().gather(1, idx), 2048)
+            del m16
 
         ref_configs.models[size]["DFINECriterion"]["losses"] = ["vfl", "boxes", "local"]  # build_loss appends in place
         crit = build_loss(size, 80, 0.0, seg)

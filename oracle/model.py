@@ -320,6 +320,8 @@ def decoder(sd, cfg, feats, inner_feats, targets, training, enable_mask_head=Fal
     topk_ind = inject.get("topk_ind")
     if topk_ind is None:
         topk_ind = torch.topk(enc_logits.max(-1).values, Q, dim=-1).indices  # _select_topk :894
+    if inject.get("return_topk"):  # test hook: just the selected token indices
+        return topk_ind
     gather = lambda t: t.gather(1, topk_ind.unsqueeze(-1).expand(-1, -1, t.shape[-1]))
     topk_mem, topk_logits = gather(out_mem), gather(enc_logits)
     topk_anchor = gather(anchors.expand(B, -1, -1))

@@ -52,7 +52,14 @@ def _value(name, shape):
         # class / corner / mask-embedding heads: small, so sigmoids and the 33-bin softmax are
         # not saturated (the interesting regime for loss parity)
         gain = 0.25 if any(t in name for t in ("score_head", "bbox_head", "reg_conf", "mask_head")) else 1.0
-        return r.normal(0, gain / np.sqrt(fan_in), n)
+        v = r.normal(0, gain / np.sqrt(fan_in), n).reshape(shape)
+        if len(shape) == 4:
+            # zero-mean filters: activations are all-positive (ReLU/SiLU + LAB), so a filter with a
+            # non-zero weight sum puts a large common offset on its output; BatchNorm then divides
+            # by a std much smaller than that offset and amplifies bf16 rounding ~50x (measured:
+            # 0.9 % error into stem2a's BN, 42 % out). Trained filters feeding a BN do not do that.
+            v = v - v.mean(axis=tuple(range(1, 4)), keepdims=True)
+        return v
     return r.normal(0, 0.1, n)
 
 
