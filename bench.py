@@ -1,0 +1,185 @@
+"""Benchmark of the D-FINE training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = forward (bf16 autocast) + criterion with device-side Hungarian matching + backward
+(+ gradient all-reduce over RCCL when N>1) + clip + AdamW + OneCycle + EMA on one synthetic
+COCO-shaped batch already resident in HBM. Rank 0 prints ONE JSON line: the BASELINE.json metric
+(images/sec, D-FINE-m 640x640 bf16), the roofline of the dominant hand-written kernel measured
+with HIP events inside the timed region, and a CPU baseline (the fp32 oracle on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="m")
+    ap.add_argument("--img", type=int, default=640)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--gts", type=int, default=8, help="ground truths per image (8 => 192 denoising queries)")
+    ap.add_argument("--task", default="detect", choices=["detect", "segment"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def msda_algorithmic_bytes(B, Lq, nH, P, c, elem):
+    """Per launch, DESIGN.md 'Kernels': fwd = corner segments read + loc/attn read + out written;
+    bwd = the same reads (value corners, loc, attn, grad_out) + fp32 atomic segments + grad_loc/attn."""
+    corners = B * Lq * nH * P * 4 * c
+    side = B * Lq * nH * P * 12
+    io = B * Lq * nH * c * elem
+    return {"msda_fwd": corners * elem + side + io, "msda_bwd": corners * elem + side + io + corners * 4 + side}
+
+
+def cpu_baseline(model, args, num_classes=80):
+    """The fp32 CPU oracle (oracle/, a port of the reference's PyTorch path) on the host cores:
+    full step (forward + criterion + backward + clip + AdamW) on a bounded sample of the workload."""
+    from oracle import configs as ocfg
+    from oracle import criterion as ocrit
+    from oracle import model as omodel
+
+    from dfine_seg_amd.synth import synthetic_batch
+
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    params = []
+    for k in sd:
+        if k in trainable:
+            sd[k].requires_grad_(True)
+            params.append(sd[k])
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1.25e-4)
+    cfg = ocfg.size_cfg(args.model)
+    B = 2
+    seg = args.task == "segment"
+    images, targets = synthetic_batch(B, args.img, args.img, num_classes, args.gts, with_masks=seg, seed=7)
+
+    def one_step():
+        out = omodel.forward(sd, cfg, images, targets, training=True, enable_mask_head=seg)
+        loss = sum(ocrit.criterion(out, targets, num_classes, with_masks=seg).values())
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 0.1)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+    one_step()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < 2 or (time.perf_counter() - t0 < 10 and n < 8):
+        one_step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": B * n / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} full fp32 steps of D-FINE-{args.model} {args.img}x{args.img} at batch {B} "
+                      f"({args.gts} GT/img) through oracle/ on the host CPU"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    import __graft_entry__
+
+    __graft_entry__.build()
+    from dfine_seg_amd import _lib
+    from dfine_seg_amd.synth import synthetic_batch
+    from dfine_seg_amd.train import TrainStep
+
+    seg = args.task == "segment"
+    reducer = None
+    if world > 1:
+        from dfine_seg_amd.ddp import BucketedGradReducer
+
+        reducer = BucketedGradReducer
+    torch.manual_seed(42 + rank)  # per-rank seed like train.py:131
+    trainer = TrainStep(args.model, 80, seg, (args.img, args.img), device, total_steps=max(1000, args.steps + args.warmup + 1),
+                        grad_reducer=reducer)
+    images, targets = synthetic_batch(args.batch, args.img, args.img, 80, args.gts, with_masks=seg, seed=42 + rank, device=device)
+    images = images.contiguous(memory_format=torch.channels_last)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(images, targets)
+    timer = _lib.KernelTimer()
+    _lib.set_kernel_timer(timer)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(images, targets)
+    sync()
+    elapsed = time.perf_counter() - t0
+    _lib.set_kernel_timer(None)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_value = float(loss)
+    if not (loss_value == loss_value):
+        raise SystemExit("non-finite loss in the benchmark run")
+
+    if rank == 0:
+        spec = trainer.model.decoder.spec
+        Lq = spec.num_queries + 2 * args.gts * max(1, spec.num_denoising // max(args.gts, 1))
+        alg = msda_algorithmic_bytes(args.batch, Lq, spec.num_heads, sum(spec.num_points), spec.hidden // spec.num_heads, 2)
+        ksum = timer.summary()
+        kernels = {}
+        for name, st in ksum.items():
+            gbs = alg[name] / (st["avg_us"] * 1e-6) / 1e9
+            kernels[name] = {"launches": st["launches"], "avg_us": round(st["avg_us"], 2), "algorithmic_bytes": alg[name],
+                             "achieved_GBs": round(gbs, 1)}
+        dominant = max(ksum, key=lambda n: ksum[n]["total_ms"])
+        roofline = {"kernel": dominant, "bound": "hbm", "achieved": kernels[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(kernels[dominant]["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernels": kernels}
+        result = {
+            "metric": "images/sec training, D-FINE-m 640x640 bf16",
+            "value": round(args.batch * world * args.steps / elapsed, 2),
+            "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"D-FINE-{args.model} {args.task} {args.img}x{args.img}, per-GPU batch {args.batch}, "
+                                   f"{args.gts} GT/img ({Lq} decoder queries), COCO-80 synthetic",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            "loss": round(loss_value, 4),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(trainer.model, args)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

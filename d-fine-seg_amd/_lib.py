@@ -23,6 +23,9 @@ SIGNATURES = {
     "dfine_match_cost": [_c_void_p] * 6 + [_c_int] * 5 + [ctypes.c_float] * 5 + [_c_void_p],
     "dfine_lsap": [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p],
     "dfine_go_union": [_c_void_p] * 2 + [_c_int] * 3 + [_c_void_p],
+    "dfine_dwconv_fwd": [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p],
+    "dfine_dwconv_bwd_data": [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p],
+    "dfine_dwconv_bwd_weight": [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p],
 }
 
 ABI_VERSION = 1
@@ -95,3 +98,47 @@ def dtype_code(t):
     if t.dtype == torch.bfloat16:
         return DT_BF16
     raise DfineHipError(f"unsupported dtype {t.dtype} (float32 or bfloat16 only)")
+
+
+# --------------------------------------------------------------------------------------
+# optional per-kernel timing (bench.py): HIP events on the stream the kernel is launched on
+# --------------------------------------------------------------------------------------
+class KernelTimer:
+    """Collects (start, stop) event pairs per kernel name; ``summary()`` after a device sync."""
+
+    def __init__(self):
+        self.events = {}
+
+    def summary(self):
+        out = {}
+        for name, pairs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out[name] = {"launches": len(ms), "avg_us": 1e3 * sum(ms) / max(len(ms), 1), "total_ms": sum(ms)}
+        return out
+
+
+_timer = None
+
+
+def set_kernel_timer(timer):
+    global _timer
+    _timer = timer
+
+
+class timed:
+    """``with timed("msda_fwd"): launch`` -- a no-op unless a KernelTimer is installed."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _timer is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record(torch.cuda.current_stream())
+
+    def __exit__(self, *exc):
+        if _timer is not None:
+            stop = torch.cuda.Event(enable_timing=True)
+            stop.record(torch.cuda.current_stream())
+            _timer.events.setdefault(self.name, []).append((self.start, stop))
+        return False

@@ -1,0 +1,287 @@
+// Depthwise kxk convolutions (k in {3,5}, stride in {1,2}, pad (k-1)/2, no bias) on channel-last
+// maps: the 5x5 light-block convs and 3x3 stride-2 downsamples of HGNetv2 and the SCDown convs of
+// the encoder (reference src/d_fine/arch/hgnetv2.py:83-112,295-304, hybrid_encoder.py:96-103,
+// all nn.Conv2d(groups=channels)). These have ~k*k MACs per byte moved: HBM/L2-bound, no MFMA.
+// The stock path (MIOpen) falls back to naive / generic grouped-conv kernels for them: 6.4 ms per
+// weight-gradient call measured at B=32 (profiles/), for ~13 MB of traffic.
+//
+// Layout: x [B, H, W, C], y [B, OH, OW, C] (T = bf16 or f32), w [C, k, k] f32 (the fp32 master
+// weight, read directly: no per-step cast), dw [C, k, k] f32.
+#include "common.h"
+
+namespace dfine {
+
+struct DwGeom {
+  int B, H, W, C, OH, OW;
+};
+
+template <int K>
+__device__ __forceinline__ void stage_weights(float* w_s, const float* __restrict__ w, int c_base,
+                                              int c_count, int tid, int nthreads) {
+  // w_s[tap][c] <- w[(c_base + c)][tap]: channel innermost so a thread's channels are contiguous
+  for (int i = tid; i < K * K * c_count; i += nthreads) {
+    const int tap = i / c_count, c = i - tap * c_count;
+    w_s[i] = w[(size_t)(c_base + c) * (K * K) + tap];
+  }
+}
+
+// Forward: one thread = one output pixel x VEC channels. blockDim = (channel groups, pixels).
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x,
+                                                         const float* __restrict__ w,
+                                                         T* __restrict__ y, DwGeom g, int n_pix) {
+  constexpr int VEC = VecTraits<T>::kElems;
+  constexpr int PAD = (K - 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) float w_s[];
+  const int c_slice = blockDim.x * VEC;
+  const int c_base = blockIdx.y * c_slice;
+  stage_weights<K>(w_s, w, c_base, c_slice, threadIdx.y * blockDim.x + threadIdx.x, blockDim.x * blockDim.y);
+  __syncthreads();
+  const int pix = blockIdx.x * blockDim.y + threadIdx.y;
+  if (pix >= n_pix) return;
+  const int ox = pix % g.OW, oy = (pix / g.OW) % g.OH, b = pix / (g.OW * g.OH);
+  const int c_loc = threadIdx.x * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  const T* xb = x + (size_t)b * g.H * g.W * g.C + c_base + c_loc;
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int iy = oy * S + ky - PAD;
+    if (iy < 0 || iy >= g.H) continue;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const int ix = ox * S + kx - PAD;
+      if (ix < 0 || ix >= g.W) continue;
+      float v[VEC];
+      VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(xb + ((size_t)iy * g.W + ix) * g.C), v);
+      const float* wt = w_s + (ky * K + kx) * c_slice + c_loc;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += v[i] * wt[i];
+    }
+  }
+  *reinterpret_cast<Vec16*>(y + (size_t)pix * g.C + c_base + c_loc) = VecTraits<T>::pack(acc);
+}
+
+// Backward w.r.t. the input: dx[iy,ix] = sum over taps of dy[(iy+pad-ky)/S, (ix+pad-kx)/S] * w[ky,kx].
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const T* __restrict__ dy,
+                                                              const float* __restrict__ w,
+                                                              T* __restrict__ dx, DwGeom g,
+                                                              int n_pix) {
+  constexpr int VEC = VecTraits<T>::kElems;
+  constexpr int PAD = (K - 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) float w_s[];
+  const int c_slice = blockDim.x * VEC;
+  const int c_base = blockIdx.y * c_slice;
+  stage_weights<K>(w_s, w, c_base, c_slice, threadIdx.y * blockDim.x + threadIdx.x, blockDim.x * blockDim.y);
+  __syncthreads();
+  const int pix = blockIdx.x * blockDim.y + threadIdx.y;  // input pixel
+  if (pix >= n_pix) return;
+  const int ix = pix % g.W, iy = (pix / g.W) % g.H, b = pix / (g.W * g.H);
+  const int c_loc = threadIdx.x * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  const T* dyb = dy + (size_t)b * g.OH * g.OW * g.C + c_base + c_loc;
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int ny = iy + PAD - ky;
+    if (ny < 0 || (ny % S) != 0) continue;
+    const int oy = ny / S;
+    if (oy >= g.OH) continue;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const int nx = ix + PAD - kx;
+      if (nx < 0 || (nx % S) != 0) continue;
+      const int ox = nx / S;
+      if (ox >= g.OW) continue;
+      float v[VEC];
+      VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(dyb + ((size_t)oy * g.OW + ox) * g.C), v);
+      const float* wt = w_s + (ky * K + kx) * c_slice + c_loc;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += v[i] * wt[i];
+    }
+  }
+  *reinterpret_cast<Vec16*>(dx + (size_t)pix * g.C + c_base + c_loc) = VecTraits<T>::pack(acc);
+}
+
+// Backward w.r.t. the weights: dw[c][tap] = sum over (b,oy,ox) of dy[b,oy,ox,c] * x[b,iy,ix,c].
+// One thread = 4 channels x a strided set of output pixels, K*K*4 fp32 partial sums in registers;
+// partials of the block's pixel rows are summed through LDS, then one float atomic per (c, tap)
+// per block into dw (zeroed by the caller).
+template <typename T>
+struct Quad;  // 4 channels as one 8-byte (bf16) or 16-byte (f32) load
+template <>
+struct Quad<bf16_t> {
+  __device__ static __forceinline__ void load(const bf16_t* p, float* f) {
+    const uint2 q = *reinterpret_cast<const uint2*>(p);
+    f[0] = __uint_as_float(q.x << 16);
+    f[1] = __uint_as_float(q.x & 0xffff0000u);
+    f[2] = __uint_as_float(q.y << 16);
+    f[3] = __uint_as_float(q.y & 0xffff0000u);
+  }
+};
+template <>
+struct Quad<float> {
+  __device__ static __forceinline__ void load(const float* p, float* f) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w;
+  }
+};
+
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x,
+                                                                const T* __restrict__ dy,
+                                                                float* __restrict__ dw, DwGeom g,
+                                                                int n_pix, int pix_per_thread) {
+  constexpr int PAD = (K - 1) / 2;
+  constexpr int KK = K * K;
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [blockDim.y][blockDim.x][KK*4]
+  const int c0 = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
+  float acc[KK][4];
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = 0.f;
+  const int first = blockIdx.x * blockDim.y * pix_per_thread + threadIdx.y;
+  for (int n = 0; n < pix_per_thread; ++n) {
+    const int pix = first + n * blockDim.y;
+    if (pix >= n_pix) break;
+    const int ox = pix % g.OW, oy = (pix / g.OW) % g.OH, b = pix / (g.OW * g.OH);
+    float d[4];
+    Quad<T>::load(dy + (size_t)pix * g.C + c0, d);
+    const T* xb = x + (size_t)b * g.H * g.W * g.C + c0;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = oy * S + ky - PAD;
+      if (iy < 0 || iy >= g.H) continue;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int ix = ox * S + kx - PAD;
+        if (ix < 0 || ix >= g.W) continue;
+        float v[4];
+        Quad<T>::load(xb + ((size_t)iy * g.W + ix) * g.C, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[ky * K + kx][i] += d[i] * v[i];
+      }
+    }
+  }
+  // block reduction over threadIdx.y
+  float* mine = red + ((size_t)threadIdx.y * blockDim.x + threadIdx.x) * (KK * 4);
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mine[t * 4 + i] = acc[t][i];
+  __syncthreads();
+  const int per_col = KK * 4;
+  for (int e = threadIdx.y; e < per_col; e += blockDim.y) {
+    float s = 0.f;
+    for (int r = 0; r < (int)blockDim.y; ++r) s += red[((size_t)r * blockDim.x + threadIdx.x) * per_col + e];
+    const int t = e / 4, i = e % 4;
+    atomicAdd(dw + (size_t)(c0 + i) * KK + t, s);
+  }
+}
+
+static int largest_divisor_leq(int n, int cap) {
+  for (int d = cap; d >= 1; --d)
+    if (n % d == 0) return d;
+  return 1;
+}
+
+template <typename T, int K, int S>
+static int run_fwd_or_bwd_data(bool fwd, const void* in, const float* w, void* out, const DwGeom& g,
+                               hipStream_t st) {
+  constexpr int VEC = VecTraits<T>::kElems;
+  if (g.C % VEC != 0) return DFINE_E_UNSUPPORTED;
+  const int cgb = largest_divisor_leq(g.C / VEC, 32);
+  const int pb = 256 / cgb;
+  const long long n_pix = fwd ? (long long)g.B * g.OH * g.OW : (long long)g.B * g.H * g.W;
+  dim3 block(cgb, pb), grid((unsigned)((n_pix + pb - 1) / pb), g.C / (cgb * VEC));
+  const size_t lds = (size_t)K * K * cgb * VEC * sizeof(float);
+  if (fwd)
+    hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, S>), grid, block, lds, st, (const T*)in, w, (T*)out, g, (int)n_pix);
+  else
+    hipLaunchKernelGGL((dwconv_bwd_data_kernel<T, K, S>), grid, block, lds, st, (const T*)in, w, (T*)out, g, (int)n_pix);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int K, int S>
+static int run_bwd_weight(const void* x, const void* dy, float* dw, const DwGeom& g, hipStream_t st) {
+  if (g.C % 4 != 0) return DFINE_E_UNSUPPORTED;
+  const int cgb = largest_divisor_leq(g.C / 4, 32);
+  const int pb = (K == 5 ? 128 : 256) / cgb;  // K*K*4 floats of LDS per thread: keep the block under 64 KiB
+  const long long n_pix = (long long)g.B * g.OH * g.OW;
+  // enough blocks to fill the chip (~2k) but >= 16 pixels per thread so atomics stay few
+  int ppt = (int)((n_pix + (long long)pb * 2048 - 1) / ((long long)pb * 2048));
+  if (ppt < 16) ppt = 16;
+  dim3 block(cgb, pb), grid((unsigned)((n_pix + (long long)pb * ppt - 1) / ((long long)pb * ppt)), g.C / (cgb * 4));
+  const size_t lds = (size_t)pb * cgb * K * K * 4 * sizeof(float);
+  if (lds > 64 * 1024) return DFINE_E_UNSUPPORTED;
+  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, S>), grid, block, lds, st, (const T*)x, (const T*)dy, dw, g,
+                     (int)n_pix, ppt);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
+#define DFINE_DW_DISPATCH(CALL)                                                     \
+  do {                                                                              \
+    if (dtype == DFINE_DT_BF16) {                                                   \
+      if (k == 3 && stride == 1) return CALL(bf16_t, 3, 1);                         \
+      if (k == 3 && stride == 2) return CALL(bf16_t, 3, 2);                         \
+      if (k == 5 && stride == 1) return CALL(bf16_t, 5, 1);                         \
+      if (k == 5 && stride == 2) return CALL(bf16_t, 5, 2);                         \
+    } else if (dtype == DFINE_DT_F32) {                                             \
+      if (k == 3 && stride == 1) return CALL(float, 3, 1);                          \
+      if (k == 3 && stride == 2) return CALL(float, 3, 2);                          \
+      if (k == 5 && stride == 1) return CALL(float, 5, 1);                          \
+      if (k == 5 && stride == 2) return CALL(float, 5, 2);                          \
+    }                                                                               \
+    return DFINE_E_UNSUPPORTED;                                                     \
+  } while (0)
+
+static int make_dw_geom(DwGeom* g, int B, int H, int W, int C, int k, int stride) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return DFINE_E_BADARG;
+  if ((k != 3 && k != 5) || (stride != 1 && stride != 2)) return DFINE_E_UNSUPPORTED;
+  const int pad = (k - 1) / 2;
+  *g = DwGeom{B, H, W, C, (H + 2 * pad - k) / stride + 1, (W + 2 * pad - k) / stride + 1};
+  return 0;
+}
+
+}  // namespace dfine
+
+using namespace dfine;
+
+extern "C" int dfine_dwconv_fwd(const void* x, const float* w, void* y, int dtype, int B, int H,
+                                int W, int C, int k, int stride, void* stream) {
+  if (!x || !w || !y) return DFINE_E_BADARG;
+  DwGeom g;
+  if (int rc = make_dw_geom(&g, B, H, W, C, k, stride)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(T, K, S) run_fwd_or_bwd_data<T, K, S>(true, x, w, y, g, st)
+  DFINE_DW_DISPATCH(CALL);
+#undef CALL
+}
+
+extern "C" int dfine_dwconv_bwd_data(const void* dy, const float* w, void* dx, int dtype, int B,
+                                     int H, int W, int C, int k, int stride, void* stream) {
+  if (!dy || !w || !dx) return DFINE_E_BADARG;
+  DwGeom g;
+  if (int rc = make_dw_geom(&g, B, H, W, C, k, stride)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(T, K, S) run_fwd_or_bwd_data<T, K, S>(false, dy, w, dx, g, st)
+  DFINE_DW_DISPATCH(CALL);
+#undef CALL
+}
+
+extern "C" int dfine_dwconv_bwd_weight(const void* x, const void* dy, float* dw, int dtype, int B,
+                                       int H, int W, int C, int k, int stride, void* stream) {
+  if (!x || !dy || !dw) return DFINE_E_BADARG;
+  DwGeom g;
+  if (int rc = make_dw_geom(&g, B, H, W, C, k, stride)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(T, K, S) run_bwd_weight<T, K, S>(x, dy, dw, g, st)
+  DFINE_DW_DISPATCH(CALL);
+#undef CALL
+}

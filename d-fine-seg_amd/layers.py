@@ -8,6 +8,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
+
 
 class FrozenBatchNorm2d(nn.Module):
     """Affine + statistics as fixed buffers (reference src/d_fine/arch/common.py:29-67; eps inside
@@ -64,7 +66,12 @@ class ConvNorm(nn.Module):
             self.lab = LearnableAffine()
 
     def forward(self, x):
-        x = getattr(self, self.norm_name)(self.conv(x))
+        conv = self.conv
+        if conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1:
+            x = ops.depthwise_conv2d(x, conv.weight, conv.stride[0])  # HIP: MIOpen has no fast path here
+        else:
+            x = conv(x)
+        x = getattr(self, self.norm_name)(x)
         if self.act is not None:
             x = self.act(x)
         if hasattr(self, "lab"):

@@ -30,10 +30,11 @@ class _MSDeformAttnCore(torch.autograd.Function):
         out = torch.empty(B, Lq, nH * c, dtype=value.dtype, device=value.device)
         hw = _lib.i32_array(v for pair in level_hw for v in pair)
         npts = _lib.i32_array(num_points)
-        rc = lib.dfine_msda_fwd(
-            _lib.ptr(value), _lib.dtype_code(value), _lib.ptr(loc), _lib.ptr(attn), _lib.ptr(out),
-            B, S, Lq, nH, c, len(num_points), hw, npts, _lib.stream_ptr(),
-        )
+        with _lib.timed("msda_fwd"):
+            rc = lib.dfine_msda_fwd(
+                _lib.ptr(value), _lib.dtype_code(value), _lib.ptr(loc), _lib.ptr(attn), _lib.ptr(out),
+                B, S, Lq, nH, c, len(num_points), hw, npts, _lib.stream_ptr(),
+            )
         _lib.check(rc, "dfine_msda_fwd")
         ctx.save_for_backward(value, loc, attn)
         ctx.geom = (tuple(map(tuple, level_hw)), tuple(num_points))
@@ -52,11 +53,12 @@ class _MSDeformAttnCore(torch.autograd.Function):
         grad_attn = torch.empty_like(attn)
         hw = _lib.i32_array(v for pair in level_hw for v in pair)
         npts = _lib.i32_array(num_points)
-        rc = lib.dfine_msda_bwd(
-            _lib.ptr(value), _lib.dtype_code(value), _lib.ptr(loc), _lib.ptr(attn),
-            _lib.ptr(grad_out), _lib.ptr(grad_value), _lib.ptr(grad_loc), _lib.ptr(grad_attn),
-            B, S, Lq, nH, c, len(num_points), hw, npts, _lib.stream_ptr(),
-        )
+        with _lib.timed("msda_bwd"):
+            rc = lib.dfine_msda_bwd(
+                _lib.ptr(value), _lib.dtype_code(value), _lib.ptr(loc), _lib.ptr(attn),
+                _lib.ptr(grad_out), _lib.ptr(grad_value), _lib.ptr(grad_loc), _lib.ptr(grad_attn),
+                B, S, Lq, nH, c, len(num_points), hw, npts, _lib.stream_ptr(),
+            )
         _lib.check(rc, "dfine_msda_bwd")
         return grad_value.to(value.dtype), grad_loc, grad_attn, None, None
 
@@ -137,3 +139,64 @@ def go_union(gt_of_query):
     rc = lib.dfine_go_union(_lib.ptr(gt_of_query), _lib.ptr(go), H, B, Q, _lib.stream_ptr())
     _lib.check(rc, "dfine_go_union")
     return go
+
+
+class _DepthwiseConv2d(torch.autograd.Function):
+    """Channel-last depthwise conv; see include/dfine_hip.h (dfine_dwconv_*)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride):
+        _lib.require_gpu(x, weight)
+        lib = _lib.load()
+        B, C, H, W = x.shape
+        k = weight.shape[-1]
+        xl = x.permute(0, 2, 3, 1)  # NHWC view of a channels_last tensor
+        if not xl.is_contiguous():
+            xl = xl.contiguous()
+        w = weight.detach().float().reshape(C, k, k).contiguous()
+        pad = (k - 1) // 2
+        OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        y = torch.empty(B, OH, OW, C, dtype=xl.dtype, device=x.device)
+        with _lib.timed("dwconv_fwd"):
+            rc = lib.dfine_dwconv_fwd(_lib.ptr(xl), _lib.ptr(w), _lib.ptr(y), _lib.dtype_code(xl),
+                                      B, H, W, C, k, stride, _lib.stream_ptr())
+        _lib.check(rc, "dfine_dwconv_fwd")
+        ctx.save_for_backward(xl, w)
+        ctx.cfg = (stride, k, weight.dtype)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        xl, w = ctx.saved_tensors
+        stride, k, w_dtype = ctx.cfg
+        lib = _lib.load()
+        B, H, W, C = xl.shape
+        gy = grad_y.permute(0, 2, 3, 1).to(xl.dtype)
+        if not gy.is_contiguous():
+            gy = gy.contiguous()
+        st = _lib.stream_ptr()
+        code = _lib.dtype_code(xl)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(xl)
+            with _lib.timed("dwconv_bwd_data"):
+                rc = lib.dfine_dwconv_bwd_data(_lib.ptr(gy), _lib.ptr(w), _lib.ptr(dx), code, B, H, W, C, k, stride, st)
+            _lib.check(rc, "dfine_dwconv_bwd_data")
+            dx = dx.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros(C, 1, k, k, dtype=torch.float32, device=xl.device)
+            with _lib.timed("dwconv_bwd_weight"):
+                rc = lib.dfine_dwconv_bwd_weight(_lib.ptr(xl), _lib.ptr(gy), _lib.ptr(dw), code, B, H, W, C, k, stride, st)
+            _lib.check(rc, "dfine_dwconv_bwd_weight")
+            dw = dw.to(w_dtype)
+        return dx, dw, None
+
+
+def depthwise_conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1) -> torch.Tensor:
+    """MI355X replacement for ``F.conv2d(x, weight, None, stride, (k-1)//2, 1, groups=C)`` with
+    ``weight`` [C, 1, k, k] (k in {3, 5}): x [B, C, H, W] in channels_last memory (float32 or
+    bfloat16) -> y [B, C, OH, OW] channels_last, same dtype. The fp32 master weight is read
+    directly (no autocast cast)."""
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    return _DepthwiseConv2d.apply(x, weight, int(stride))

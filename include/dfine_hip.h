@@ -111,6 +111,23 @@ int dfine_lsap(const float* cost, const int32_t* num_gt, int32_t* query_of_gt,
  */
 int dfine_go_union(const int32_t* gt_of_query, int32_t* go, int H, int B, int Q, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Depthwise k x k convolution, channel-last. Replaces nn.Conv2d(C, C, k, stride, padding=(k-1)//2,
+ * groups=C, bias=False) forward/backward as used by LightConvBNAct.conv2 and HG_Stage.downsample
+ * (src/d_fine/arch/hgnetv2.py:83-112, 295-304) and SCDown.cv2 (hybrid_encoder.py:96-103).
+ *
+ *   x  [B, H, W, C]    y / dy [B, OH, OW, C]   bf16 or f32 (dtype), OH = (H + 2*pad - k)/stride + 1
+ *   w  [C, k, k] f32   (nn.Conv2d weight [C,1,k,k], fp32 master copy)
+ *   dw [C, k, k] f32   ACCUMULATED with float atomics: the caller zeroes it
+ * Supported: k in {3,5}, stride in {1,2}, C % 8 == 0 (bf16) / C % 4 == 0 (f32).
+ * ------------------------------------------------------------------------------------- */
+int dfine_dwconv_fwd(const void* x, const float* w, void* y, int dtype, int B, int H, int W, int C,
+                     int k, int stride, void* stream);
+int dfine_dwconv_bwd_data(const void* dy, const float* w, void* dx, int dtype, int B, int H, int W,
+                          int C, int k, int stride, void* stream);
+int dfine_dwconv_bwd_weight(const void* x, const void* dy, float* dw, int dtype, int B, int H, int W,
+                            int C, int k, int stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
