@@ -39,15 +39,6 @@ def parse():
     return ap.parse_args()
 
 
-def msda_algorithmic_bytes(B, Lq, nH, P, c, elem):
-    """Per launch, DESIGN.md 'Kernels': fwd = corner segments read + loc/attn read + out written;
-    bwd = the same reads (value corners, loc, attn, grad_out) + fp32 atomic segments + grad_loc/attn."""
-    corners = B * Lq * nH * P * 4 * c
-    side = B * Lq * nH * P * 12
-    io = B * Lq * nH * c * elem
-    return {"msda_fwd": corners * elem + side + io, "msda_bwd": corners * elem + side + io + corners * 4 + side}
-
-
 def cpu_baseline(model, args, num_classes=80):
     """The fp32 CPU oracle (oracle/, a port of the reference's PyTorch path) on the host cores:
     full step (forward + criterion + backward + clip + AdamW) on a bounded sample of the workload."""
@@ -149,13 +140,14 @@ def main():
     if rank == 0:
         spec = trainer.model.decoder.spec
         Lq = spec.num_queries + 2 * args.gts * max(1, spec.num_denoising // max(args.gts, 1))
-        alg = msda_algorithmic_bytes(args.batch, Lq, spec.num_heads, sum(spec.num_points), spec.hidden // spec.num_heads, 2)
         ksum = timer.summary()
         kernels = {}
         for name, st in ksum.items():
-            gbs = alg[name] / (st["avg_us"] * 1e-6) / 1e9
-            kernels[name] = {"launches": st["launches"], "avg_us": round(st["avg_us"], 2), "algorithmic_bytes": alg[name],
-                             "achieved_GBs": round(gbs, 1)}
+            gbs = st["avg_bytes"] / (st["avg_us"] * 1e-6) / 1e9
+            kernels[name] = {"launches": st["launches"], "avg_us": round(st["avg_us"], 2),
+                             "algorithmic_bytes": int(st["avg_bytes"]), "achieved_GBs": round(gbs, 1),
+                             "ms_per_step": round(st["total_ms"] / args.steps, 3)}
+        # the hand-written kernel the step spends most time in (all of them are HBM/L2-bound)
         dominant = max(ksum, key=lambda n: ksum[n]["total_ms"])
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": kernels[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(kernels[dominant]["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": None,

@@ -111,9 +111,11 @@ class KernelTimer:
 
     def summary(self):
         out = {}
-        for name, pairs in self.events.items():
-            ms = [a.elapsed_time(b) for a, b in pairs]
-            out[name] = {"launches": len(ms), "avg_us": 1e3 * sum(ms) / max(len(ms), 1), "total_ms": sum(ms)}
+        for name, recs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            nbytes = sum(n for _, _, n in recs)
+            out[name] = {"launches": len(ms), "avg_us": 1e3 * sum(ms) / max(len(ms), 1), "total_ms": sum(ms),
+                         "avg_bytes": nbytes / max(len(ms), 1)}
         return out
 
 
@@ -126,10 +128,11 @@ def set_kernel_timer(timer):
 
 
 class timed:
-    """``with timed("msda_fwd"): launch`` -- a no-op unless a KernelTimer is installed."""
+    """``with timed("msda_fwd", algorithmic_bytes): launch`` -- a no-op unless a KernelTimer is
+    installed. ``nbytes`` is the launch's ALGORITHMIC traffic ("Kernels")."""
 
-    def __init__(self, name):
-        self.name = name
+    def __init__(self, name, nbytes=0):
+        self.name, self.nbytes = name, nbytes
 
     def __enter__(self):
         if _timer is not None:
@@ -140,5 +143,5 @@ class timed:
         if _timer is not None:
             stop = torch.cuda.Event(enable_timing=True)
             stop.record(torch.cuda.current_stream())
-            _timer.events.setdefault(self.name, []).append((self.start, stop))
+            _timer.events.setdefault(self.name, []).append((self.start, stop, self.nbytes))
         return False

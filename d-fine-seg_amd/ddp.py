@@ -1,0 +1,135 @@
+"""Data-parallel gradient exchange for one process per GPU over RCCL (backend "nccl" on ROCm),
+replacing the reference's ``DistributedDataParallel`` wrap (src/dl/train.py:157-169, collectives
+C1-C3 in SURVEY.md 2.3).
+
+  * gradients live in a few large flat fp32 buckets (``p.grad`` are views into them), filled in
+    reverse registration order -- decoder, encoder, backbone -- which is the order backward produces
+    them;
+  * when the last gradient of a bucket has been accumulated, the bucket is all-reduced (mean) on a
+    side HIP stream, overlapping the rest of backward; ``finish()`` joins before clip/optimizer;
+  * xGMI is point-to-point (7 links per GPU): few large messages beat DDP's 25 MB default, so the
+    default is 4 buckets for D-FINE-m's 78 MB of gradients;
+  * parameters that received no gradient this step (e.g. the denoising embedding on a batch with no
+    ground truth) contribute zeros -- the reference's ``find_unused_parameters=False`` DDP would
+    raise on the following iteration instead;
+  * parameters are broadcast from rank 0 once; BatchNorm statistics stay per-rank (DDP re-broadcasts
+    all buffers every forward, C3).
+"""
+import torch
+import torch.distributed as dist
+
+
+def init_distributed():
+    """Process group from the torchrun environment (reference dist_utils.py:12-43): RCCL when a
+    GPU is present, Gloo otherwise. Returns (rank, world_size, local_rank)."""
+    import os
+
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
+        return 0, 1, 0
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", 0))
+    if not dist.is_initialized():
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+    return rank, world, local
+
+
+def assign_buckets(named_params, num_buckets=4, min_bucket_bytes=1 << 20):
+    """Split trainable parameters, LAST registered first, into ``num_buckets`` contiguous groups of
+    roughly equal byte size. Returns a list of lists of (name, param)."""
+    params = [(n, p) for n, p in named_params if p.requires_grad][::-1]
+    total = sum(p.numel() * 4 for _, p in params)
+    target = max(total / max(num_buckets, 1), min_bucket_bytes)
+    buckets, cur, cur_bytes = [], [], 0
+    for n, p in params:
+        cur.append((n, p))
+        cur_bytes += p.numel() * 4
+        if cur_bytes >= target and len(buckets) < num_buckets - 1:
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+    if cur:
+        buckets.append(cur)
+    return buckets
+
+
+class _Bucket:
+    def __init__(self, params, device):
+        self.params = params
+        self.flat = torch.zeros(sum(p.numel() for _, p in params), dtype=torch.float32, device=device)
+        offset = 0
+        for _, p in params:
+            p.grad = self.flat[offset : offset + p.numel()].view_as(p)  # autograd accumulates in place
+            offset += p.numel()
+        self.pending = len(params)
+        self.work = None
+
+
+class BucketedGradReducer:
+    """``reducer = BucketedGradReducer(model)`` before training; per step: backward (hooks fire),
+    ``reducer.finish()``, optimizer, ``reducer.zero_grad()``."""
+
+    def __init__(self, model, num_buckets=4, process_group=None, broadcast_parameters=True):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("BucketedGradReducer needs an initialised process group")
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        device = next(model.parameters()).device
+        self.on_gpu = device.type == "cuda"
+        self.side_stream = torch.cuda.Stream(device) if self.on_gpu else None
+        self.backend_has_avg = dist.get_backend(process_group) == "nccl"
+        if broadcast_parameters:  # C2: everyone starts from rank 0's weights (buffers included, once)
+            with torch.no_grad():
+                for t in list(model.parameters()) + list(model.buffers()):
+                    dist.broadcast(t, src=0, group=process_group)
+        self.buckets = [_Bucket(b, device) for b in assign_buckets(model.named_parameters(), num_buckets)]
+        self._owner = {}
+        for b in self.buckets:
+            for _, p in b.params:
+                self._owner[p] = b
+                p.register_post_accumulate_grad_hook(self._on_grad_ready)
+
+    # ------------------------------------------------------------------ hooks
+    def _on_grad_ready(self, param):
+        bucket = self._owner[param]
+        bucket.pending -= 1
+        if bucket.pending == 0:
+            self._launch(bucket)
+
+    def _launch(self, bucket):
+        if bucket.work is not None:
+            return
+        if self.on_gpu:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+            self.side_stream.wait_event(ready)  # the bucket's last gradient has been written
+            with torch.cuda.stream(self.side_stream):
+                bucket.work = self._all_reduce(bucket.flat)
+        else:
+            bucket.work = self._all_reduce(bucket.flat)
+
+    def _all_reduce(self, flat):
+        if self.backend_has_avg:
+            return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        work.wait()
+        flat.div_(self.world)
+        return work
+
+    # ------------------------------------------------------------------ per-step API
+    def finish(self):
+        """Reduce buckets whose gradients never all arrived (unused parameters count as zero), then
+        make the current stream wait for every all-reduce."""
+        for b in self.buckets:
+            if b.work is None:
+                self._launch(b)
+        for b in self.buckets:
+            b.work.wait()
+            if self.on_gpu:
+                torch.cuda.current_stream().wait_stream(self.side_stream)
+            b.work, b.pending = None, len(b.params)
+
+    def zero_grad(self):
+        for b in self.buckets:
+            b.flat.zero_()

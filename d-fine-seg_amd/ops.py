@@ -9,6 +9,17 @@ import torch
 from . import _lib
 
 
+def msda_algorithmic_bytes(B, Lq, nH, P, c, elem):
+    """(forward, backward) algorithmic bytes of one deformable-attention launch:
+    fwd = 4 corner segments of c elements per sampling point + (x, y, weight) per point + the output;
+    bwd = the same reads (value corners, loc, attn, grad_out) + one fp32 atomic segment per corner
+    + grad_loc / grad_attn."""
+    corners = B * Lq * nH * P * 4 * c
+    side = B * Lq * nH * P * 12
+    io = B * Lq * nH * c * elem
+    return corners * elem + side + io, corners * elem + side + io + corners * 4 + side
+
+
 class _MSDeformAttnCore(torch.autograd.Function):
     """Gather behind decoder cross-attention; see include/dfine_hip.h (dfine_msda_fwd/bwd)."""
 
@@ -30,7 +41,7 @@ class _MSDeformAttnCore(torch.autograd.Function):
         out = torch.empty(B, Lq, nH * c, dtype=value.dtype, device=value.device)
         hw = _lib.i32_array(v for pair in level_hw for v in pair)
         npts = _lib.i32_array(num_points)
-        with _lib.timed("msda_fwd"):
+        with _lib.timed("msda_fwd", msda_algorithmic_bytes(B, Lq, nH, P, c, value.element_size())[0]):
             rc = lib.dfine_msda_fwd(
                 _lib.ptr(value), _lib.dtype_code(value), _lib.ptr(loc), _lib.ptr(attn), _lib.ptr(out),
                 B, S, Lq, nH, c, len(num_points), hw, npts, _lib.stream_ptr(),
@@ -53,7 +64,7 @@ class _MSDeformAttnCore(torch.autograd.Function):
         grad_attn = torch.empty_like(attn)
         hw = _lib.i32_array(v for pair in level_hw for v in pair)
         npts = _lib.i32_array(num_points)
-        with _lib.timed("msda_bwd"):
+        with _lib.timed("msda_bwd", msda_algorithmic_bytes(B, Lq, nH, loc.shape[3], c, value.element_size())[1]):
             rc = lib.dfine_msda_bwd(
                 _lib.ptr(value), _lib.dtype_code(value), _lib.ptr(loc), _lib.ptr(attn),
                 _lib.ptr(grad_out), _lib.ptr(grad_value), _lib.ptr(grad_loc), _lib.ptr(grad_attn),
@@ -157,7 +168,7 @@ class _DepthwiseConv2d(torch.autograd.Function):
         pad = (k - 1) // 2
         OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         y = torch.empty(B, OH, OW, C, dtype=xl.dtype, device=x.device)
-        with _lib.timed("dwconv_fwd"):
+        with _lib.timed("dwconv_fwd", (xl.numel() + y.numel()) * xl.element_size() + w.numel() * 4):
             rc = lib.dfine_dwconv_fwd(_lib.ptr(xl), _lib.ptr(w), _lib.ptr(y), _lib.dtype_code(xl),
                                       B, H, W, C, k, stride, _lib.stream_ptr())
         _lib.check(rc, "dfine_dwconv_fwd")
@@ -179,13 +190,13 @@ class _DepthwiseConv2d(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(xl)
-            with _lib.timed("dwconv_bwd_data"):
+            with _lib.timed("dwconv_bwd_data", (gy.numel() + dx.numel()) * gy.element_size() + w.numel() * 4):
                 rc = lib.dfine_dwconv_bwd_data(_lib.ptr(gy), _lib.ptr(w), _lib.ptr(dx), code, B, H, W, C, k, stride, st)
             _lib.check(rc, "dfine_dwconv_bwd_data")
             dx = dx.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             dw = torch.zeros(C, 1, k, k, dtype=torch.float32, device=xl.device)
-            with _lib.timed("dwconv_bwd_weight"):
+            with _lib.timed("dwconv_bwd_weight", (gy.numel() + xl.numel()) * gy.element_size() + w.numel() * 4):
                 rc = lib.dfine_dwconv_bwd_weight(_lib.ptr(xl), _lib.ptr(gy), _lib.ptr(dw), code, B, H, W, C, k, stride, st)
             _lib.check(rc, "dfine_dwconv_bwd_weight")
             dw = dw.to(w_dtype)

@@ -79,7 +79,10 @@ class TrainStep:
             torch.nn.utils.clip_grad_norm_(model.parameters(), self.clip_max_norm, foreach=True)
         self.optimizer.step()
         self.scheduler.step()
-        self.optimizer.zero_grad(set_to_none=True)
+        if self.grad_reducer is not None:
+            self.grad_reducer.zero_grad()  # grads are views into the reducer's flat buckets
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
         self.iters += 1
         if self.ema is not None:
             self.ema.update(self.iters, model)
