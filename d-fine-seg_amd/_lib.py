@@ -26,6 +26,8 @@ SIGNATURES = {
     "dfine_dwconv_fwd": [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p],
     "dfine_dwconv_bwd_data": [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p],
     "dfine_dwconv_bwd_weight": [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p],
+    "dfine_bn_act_fwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 9 + [_c_int] * 4 + [ctypes.c_float] * 2 + [_c_void_p],
+    "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 11 + [_c_int] * 4 + [ctypes.c_float] + [_c_void_p],
 }
 
 ABI_VERSION = 1
@@ -77,7 +79,7 @@ def require_gpu(*tensors):
 
 
 def ptr(t):
-    return ctypes.c_void_p(t.data_ptr())
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
 def stream_ptr():

@@ -1,0 +1,367 @@
+// Fused training BatchNorm2d + optional addend + activation + learnable affine, channel-last.
+//
+//   z = (x - mean_c) * rstd_c * gamma_c + beta_c  (+ addend)     mean/var over (B, H, W) per channel
+//   y = lab_scale * act(z) + lab_bias                            act in {identity, relu, silu}
+//
+// This is the tail of every conv block on the path: ConvBNAct (bn -> ReLU -> LearnableAffineBlock,
+// reference src/d_fine/arch/hgnetv2.py:35-80), ConvNormLayer(_fuse) (norm -> SiLU,
+// hybrid_encoder.py:21-93) and VGGBlock (silu(bn(conv3x3) + bn(conv1x1)), hybrid_encoder.py:115-121,
+// which is what the addend is for). The stock path spends 5 launches and 4 passes over the map in the
+// forward (MIOpen mean/var, final, normalise; activation; addcmul) and ~9 in the backward; here it is
+// 2 + 2 kernels, each map read twice per direction. All four kernels are HBM-bound streaming kernels.
+//
+// x / addend / y / dy / dx / dadd: [n_pix, C] (= [B, H, W, C]) of T (bf16 or f32). Statistics are
+// accumulated as fp32 partials per thread and combined with fp64 atomics (the conv outputs of this
+// model can have |mean| >> std; fp64 keeps E[x^2] - E[x]^2 exact enough).
+#include "common.h"
+
+namespace dfine {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+
+struct NaGeom {
+  int n_pix, C;
+  int pix_per_thread;
+  int act, has_add, has_lab, training;
+  float eps, momentum;
+};
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  if (act == ACT_RELU) return fmaxf(z, 0.f);
+  if (act == ACT_SILU) return z / (1.f + __expf(-z));
+  return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act) {
+  if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == ACT_SILU) {
+    const float s = 1.f / (1.f + __expf(-z));
+    return s * (1.f + z * (1.f - s));
+  }
+  return 1.f;
+}
+
+// blockDim = (channel groups of VEC, pixel rows). Thread (cx, py) owns channels
+// [ (blockIdx.y*blockDim.x + cx)*VEC, +VEC ) and pixels blockIdx.x*blockDim.y*ppt + py + n*blockDim.y.
+template <typename T, int NQ>
+struct ColReduce {
+  // Sum NQ quantities x VEC channels over the block's pixel rows through LDS, then one fp64 atomic
+  // per (quantity, channel) per block into out[q*C + c].
+  template <int VEC>
+  __device__ static __forceinline__ void run(float (&acc)[NQ][VEC], float* red, double* out, int C, int c0) {
+    const int lanes = blockDim.x * VEC;  // channels covered by the block
+    float* mine = red + (size_t)threadIdx.y * NQ * lanes + threadIdx.x * VEC;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) mine[q * lanes + i] = acc[q][i];
+    __syncthreads();
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthreads = blockDim.x * blockDim.y;
+    for (int e = tid; e < NQ * lanes; e += nthreads) {
+      float s = 0.f;
+      for (int r = 0; r < (int)blockDim.y; ++r) s += red[(size_t)r * NQ * lanes + e];
+      const int q = e / lanes, c = e - q * lanes;
+      atomicAdd(out + (size_t)q * C + (c0 - threadIdx.x * VEC) + c, (double)s);
+    }
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, double* __restrict__ sums, NaGeom g) {
+  constexpr int VEC = VecTraits<T>::kElems;
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int c0 = (blockIdx.y * blockDim.x + threadIdx.x) * VEC;
+  float acc[2][VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[0][i] = acc[1][i] = 0.f;
+  const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
+  for (int n = 0; n < g.pix_per_thread; ++n) {
+    const int pix = first + n * blockDim.y;
+    if (pix >= g.n_pix) break;
+    float v[VEC];
+    VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(x + (size_t)pix * g.C + c0), v);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      acc[0][i] += v[i];
+      acc[1][i] += v[i] * v[i];
+    }
+  }
+  ColReduce<T, 2>::template run<VEC>(acc, red, sums, g.C, c0);
+}
+
+// mean / rstd of channel c from the fp64 sums (training) or the running statistics (eval)
+__device__ __forceinline__ void channel_stats(const double* sums, const float* running_mean,
+                                              const float* running_var, const NaGeom& g, int c,
+                                              float* mean, float* rstd, float* var_biased) {
+  if (g.training) {
+    const double m = sums[c] / g.n_pix;
+    double v = sums[g.C + c] / g.n_pix - m * m;
+    if (v < 0) v = 0;
+    *mean = (float)m;
+    *var_biased = (float)v;
+    *rstd = rsqrtf((float)v + g.eps);
+  } else {
+    *mean = running_mean[c];
+    *var_biased = running_var[c];
+    *rstd = rsqrtf(running_var[c] + g.eps);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(
+    const T* __restrict__ x, const T* __restrict__ addend, T* __restrict__ y,
+    const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ save_mean,
+    float* __restrict__ save_rstd, const float* __restrict__ lab_scale, const float* __restrict__ lab_bias, NaGeom g) {
+  constexpr int VEC = VecTraits<T>::kElems;
+  const int c0 = (blockIdx.y * blockDim.x + threadIdx.x) * VEC;
+  float scale[VEC], shift[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    float mean, rstd, var;
+    channel_stats(sums, running_mean, running_var, g, c0 + i, &mean, &rstd, &var);
+    scale[i] = rstd * gamma[c0 + i];
+    shift[i] = beta[c0 + i] - mean * scale[i];
+    if (g.training && blockIdx.x == 0 && threadIdx.y == 0) {  // one thread per channel keeps the books
+      save_mean[c0 + i] = mean;
+      save_rstd[c0 + i] = rstd;
+      const float unbiased = g.n_pix > 1 ? var * ((float)g.n_pix / (float)(g.n_pix - 1)) : var;
+      running_mean[c0 + i] = (1.f - g.momentum) * running_mean[c0 + i] + g.momentum * mean;
+      running_var[c0 + i] = (1.f - g.momentum) * running_var[c0 + i] + g.momentum * unbiased;
+    }
+  }
+  const float ls = g.has_lab ? lab_scale[0] : 1.f, lb = g.has_lab ? lab_bias[0] : 0.f;
+  const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
+  for (int n = 0; n < g.pix_per_thread; ++n) {
+    const int pix = first + n * blockDim.y;
+    if (pix >= g.n_pix) break;
+    const size_t off = (size_t)pix * g.C + c0;
+    float v[VEC], a[VEC];
+    VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(x + off), v);
+    if (g.has_add) VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(addend + off), a);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float z = v[i] * scale[i] + shift[i];
+      if (g.has_add) z += a[i];
+      v[i] = ls * act_fwd(z, g.act) + lb;
+    }
+    *reinterpret_cast<Vec16*>(y + off) = VecTraits<T>::pack(v);
+  }
+}
+
+// Backward pass 1: per channel sum(dz), sum(dz * xhat), sum(dy * act(z)) [-> d lab_scale], sum(dy) [-> d lab_bias]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const T* __restrict__ x, const T* __restrict__ addend, const T* __restrict__ dy,
+    const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ lab_scale,
+    double* __restrict__ red_out, NaGeom g) {
+  constexpr int VEC = VecTraits<T>::kElems;
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int c0 = (blockIdx.y * blockDim.x + threadIdx.x) * VEC;
+  float mean[VEC], rstd[VEC], gam[VEC], bet[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    mean[i] = save_mean[c0 + i];
+    rstd[i] = save_rstd[c0 + i];
+    gam[i] = gamma[c0 + i];
+    bet[i] = beta[c0 + i];
+  }
+  const float ls = g.has_lab ? lab_scale[0] : 1.f;
+  float acc[4][VEC];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[q][i] = 0.f;
+  const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
+  for (int n = 0; n < g.pix_per_thread; ++n) {
+    const int pix = first + n * blockDim.y;
+    if (pix >= g.n_pix) break;
+    const size_t off = (size_t)pix * g.C + c0;
+    float v[VEC], a[VEC], d[VEC];
+    VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(x + off), v);
+    VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(dy + off), d);
+    if (g.has_add) VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(addend + off), a);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float xhat = (v[i] - mean[i]) * rstd[i];
+      float z = xhat * gam[i] + bet[i];
+      if (g.has_add) z += a[i];
+      const float dz = d[i] * ls * act_grad(z, g.act);
+      acc[0][i] += dz;
+      acc[1][i] += dz * xhat;
+      acc[2][i] += d[i] * act_fwd(z, g.act);
+      acc[3][i] += d[i];
+    }
+  }
+  ColReduce<T, 4>::template run<VEC>(acc, red, red_out, g.C, c0);
+}
+
+// Backward pass 2: dx = gamma*rstd * (dz - mean(dz) - xhat*mean(dz*xhat)); dadd = dz;
+// block row 0 also publishes dgamma/dbeta (fp32) and adds its channels' share of d lab.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
+    const T* __restrict__ x, const T* __restrict__ addend, const T* __restrict__ dy,
+    const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ lab_scale,
+    const double* __restrict__ red_in, T* __restrict__ dx, T* __restrict__ dadd,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dlab, NaGeom g) {
+  constexpr int VEC = VecTraits<T>::kElems;
+  const int c0 = (blockIdx.y * blockDim.x + threadIdx.x) * VEC;
+  float mean[VEC], rstd[VEC], gam[VEC], bet[VEC], m_dz[VEC], m_dzx[VEC];
+  float lab_s = 0.f, lab_b = 0.f;
+  const float inv_n = 1.f / (float)g.n_pix;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int c = c0 + i;
+    mean[i] = save_mean[c];
+    rstd[i] = save_rstd[c];
+    gam[i] = gamma[c];
+    bet[i] = beta[c];
+    const float s_dz = (float)red_in[c], s_dzx = (float)red_in[g.C + c];
+    m_dz[i] = g.training ? s_dz * inv_n : 0.f;   // eval-mode BN: statistics are constants
+    m_dzx[i] = g.training ? s_dzx * inv_n : 0.f;
+    if (blockIdx.x == 0 && threadIdx.y == 0) {
+      dgamma[c] = s_dzx;
+      dbeta[c] = s_dz;
+      lab_s += (float)red_in[2 * g.C + c];
+      lab_b += (float)red_in[3 * g.C + c];
+    }
+  }
+  if (g.has_lab && blockIdx.x == 0 && threadIdx.y == 0) {
+    atomicAdd(dlab, lab_s);
+    atomicAdd(dlab + 1, lab_b);
+  }
+  const float ls = g.has_lab ? lab_scale[0] : 1.f;
+  const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
+  for (int n = 0; n < g.pix_per_thread; ++n) {
+    const int pix = first + n * blockDim.y;
+    if (pix >= g.n_pix) break;
+    const size_t off = (size_t)pix * g.C + c0;
+    float v[VEC], a[VEC], d[VEC];
+    VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(x + off), v);
+    VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(dy + off), d);
+    if (g.has_add) VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(addend + off), a);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float xhat = (v[i] - mean[i]) * rstd[i];
+      float z = xhat * gam[i] + bet[i];
+      if (g.has_add) z += a[i];
+      const float dz = d[i] * ls * act_grad(z, g.act);
+      a[i] = dz;
+      v[i] = gam[i] * rstd[i] * (dz - m_dz[i] - xhat * m_dzx[i]);
+    }
+    *reinterpret_cast<Vec16*>(dx + off) = VecTraits<T>::pack(v);
+    if (g.has_add) *reinterpret_cast<Vec16*>(dadd + off) = VecTraits<T>::pack(a);
+  }
+}
+
+struct NaLaunch {
+  dim3 grid, block;
+  int ppt;
+};
+
+template <typename T>
+static int plan(NaLaunch* L, int n_pix, int C, int target_blocks) {
+  constexpr int VEC = VecTraits<T>::kElems;
+  if (C % VEC != 0) return DFINE_E_UNSUPPORTED;
+  int cgb = 1;
+  for (int d = 32; d >= 1; --d)
+    if ((C / VEC) % d == 0) { cgb = d; break; }
+  const int pb = 256 / cgb;
+  const int slices = C / (cgb * VEC);
+  long long want = (long long)target_blocks / slices;
+  if (want < 1) want = 1;
+  long long ppt = ((long long)n_pix + want * pb - 1) / (want * pb);
+  if (ppt < 1) ppt = 1;
+  L->ppt = (int)ppt;
+  L->block = dim3(cgb, pb);
+  L->grid = dim3((unsigned)(((long long)n_pix + (long long)pb * ppt - 1) / ((long long)pb * ppt)), slices);
+  return 0;
+}
+
+static NaGeom make_geom(int n_pix, int C, int ppt, int act, bool has_add, bool has_lab, int training, float eps, float momentum) {
+  NaGeom g;
+  g.n_pix = n_pix; g.C = C; g.pix_per_thread = ppt; g.act = act; g.has_add = has_add; g.has_lab = has_lab;
+  g.training = training; g.eps = eps; g.momentum = momentum;
+  return g;
+}
+
+template <typename T>
+static int fwd_impl(const void* x, const void* addend, void* y, double* sums, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float* save_mean, float* save_rstd, const float* lab_scale,
+                    const float* lab_bias, int n_pix, int C, int act, int training, float eps, float momentum, hipStream_t st) {
+  constexpr int VEC = VecTraits<T>::kElems;
+  NaLaunch R, A;
+  if (int rc = plan<T>(&R, n_pix, C, 512)) return rc;   // reductions: few blocks -> few contended atomics
+  if (int rc = plan<T>(&A, n_pix, C, 2048)) return rc;  // streaming: fill the chip
+  if (training) {
+    NaGeom g = make_geom(n_pix, C, R.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, momentum);
+    const size_t lds = (size_t)R.block.y * 2 * R.block.x * VEC * sizeof(float);
+    hipLaunchKernelGGL(bn_stats_kernel<T>, R.grid, R.block, lds, st, (const T*)x, sums, g);
+    DFINE_LAUNCH_CHECK();
+  }
+  NaGeom g = make_geom(n_pix, C, A.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, momentum);
+  hipLaunchKernelGGL(bn_apply_kernel<T>, A.grid, A.block, 0, st, (const T*)x, (const T*)addend, (T*)y, sums, gamma, beta,
+                     running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, g);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+static int bwd_impl(const void* x, const void* addend, const void* dy, const float* save_mean, const float* save_rstd,
+                    const float* gamma, const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
+                    float* dgamma, float* dbeta, float* dlab, int n_pix, int C, int act, int training, float eps,
+                    hipStream_t st) {
+  constexpr int VEC = VecTraits<T>::kElems;
+  NaLaunch R, A;
+  if (int rc = plan<T>(&R, n_pix, C, 512)) return rc;
+  if (int rc = plan<T>(&A, n_pix, C, 2048)) return rc;
+  NaGeom g = make_geom(n_pix, C, R.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, 0.f);
+  const size_t lds = (size_t)R.block.y * 4 * R.block.x * VEC * sizeof(float);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy,
+                     save_mean, save_rstd, gamma, beta, lab_scale, red, g);
+  DFINE_LAUNCH_CHECK();
+  g.pix_per_thread = A.ppt;
+  hipLaunchKernelGGL(bn_bwd_dx_kernel<T>, A.grid, A.block, 0, st, (const T*)x, (const T*)addend, (const T*)dy, save_mean,
+                     save_rstd, gamma, beta, lab_scale, red, (T*)dx, (T*)dadd, dgamma, dbeta, dlab, g);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace dfine
+
+using namespace dfine;
+
+extern "C" int dfine_bn_act_fwd(const void* x, const void* addend, void* y, int dtype, double* sums,
+                                const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, float* save_mean, float* save_rstd,
+                                const float* lab_scale, const float* lab_bias, int n_pix, int C, int act, int training, float eps,
+                                float momentum, void* stream) {
+  if (!x || !y || !gamma || !beta || !running_mean || !running_var) return DFINE_E_BADARG;
+  if (training && (!sums || !save_mean || !save_rstd)) return DFINE_E_BADARG;
+  if (n_pix <= 0 || C <= 0 || act < 0 || act > 2) return DFINE_E_BADARG;
+  if ((lab_scale != nullptr) != (lab_bias != nullptr)) return DFINE_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DFINE_DT_BF16)
+    return fwd_impl<bf16_t>(x, addend, y, sums, gamma, beta, running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, n_pix, C, act, training, eps, momentum, st);
+  if (dtype == DFINE_DT_F32)
+    return fwd_impl<float>(x, addend, y, sums, gamma, beta, running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, n_pix, C, act, training, eps, momentum, st);
+  return DFINE_E_UNSUPPORTED;
+}
+
+extern "C" int dfine_bn_act_bwd(const void* x, const void* addend, const void* dy, int dtype,
+                                const float* save_mean, const float* save_rstd, const float* gamma,
+                                const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
+                                float* dgamma, float* dbeta, float* dlab, int n_pix, int C, int act,
+                                int training, float eps, void* stream) {
+  if (!x || !dy || !save_mean || !save_rstd || !gamma || !beta || !red || !dx || !dgamma || !dbeta) return DFINE_E_BADARG;
+  if ((addend != nullptr) != (dadd != nullptr)) return DFINE_E_BADARG;
+  if (lab_scale && !dlab) return DFINE_E_BADARG;
+  if (n_pix <= 0 || C <= 0 || act < 0 || act > 2) return DFINE_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DFINE_DT_BF16)
+    return bwd_impl<bf16_t>(x, addend, dy, save_mean, save_rstd, gamma, beta, lab_scale, red, dx, dadd, dgamma, dbeta, dlab, n_pix, C, act, training, eps, st);
+  if (dtype == DFINE_DT_F32)
+    return bwd_impl<float>(x, addend, dy, save_mean, save_rstd, gamma, beta, lab_scale, red, dx, dadd, dgamma, dbeta, dlab, n_pix, C, act, training, eps, st);
+  return DFINE_E_UNSUPPORTED;
+}

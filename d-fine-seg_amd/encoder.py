@@ -19,7 +19,7 @@ class RepVgg(nn.Module):
         self.conv2 = ConvNorm(c, c, 1)
 
     def forward(self, x):
-        return F.silu(self.conv1(x) + self.conv2(x))
+        return self.conv1(x, addend=self.conv2(x), act="silu")  # one fused norm+add+silu
 
 
 class CSP(nn.Module):

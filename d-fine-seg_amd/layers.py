@@ -61,22 +61,48 @@ class ConvNorm(nn.Module):
                               groups=groups, bias=False)
         self.norm_name = norm_name
         setattr(self, norm_name, FrozenBatchNorm2d(c_out) if frozen_norm else nn.BatchNorm2d(c_out))
-        self.act = _ACTS[act]
+        self.act_name = act
         if lab and act is not None:
             self.lab = LearnableAffine()
+        self._pending_batches = 0
+        self.register_state_dict_pre_hook(ConvNorm._flush_batch_counter)
 
-    def forward(self, x):
+    def forward(self, x, addend=None, act=None):
+        """``addend`` (same shape as the output) is added after the norm, before the activation;
+        ``act`` overrides the constructor's activation name (used by RepVgg: silu(a + b))."""
         conv = self.conv
         if conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1:
             x = ops.depthwise_conv2d(x, conv.weight, conv.stride[0])  # HIP: MIOpen has no fast path here
         else:
             x = conv(x)
-        x = getattr(self, self.norm_name)(x)
-        if self.act is not None:
-            x = self.act(x)
-        if hasattr(self, "lab"):
-            x = self.lab(x)
+        act_name = act if act is not None else self.act_name
+        norm = getattr(self, self.norm_name)
+        lab = getattr(self, "lab", None)
+        fused = (isinstance(norm, nn.BatchNorm2d) and ops.batch_norm_act_supported(x, conv.out_channels)
+                 and (self.training or not torch.is_grad_enabled()))
+        if fused:  # HIP: norm + addend + activation + LAB in 2 kernels (2 more in backward)
+            if self.training:
+                self._pending_batches += 1
+            return ops.batch_norm_act(
+                x, norm.weight, norm.bias, norm.running_mean, norm.running_var, act_name,
+                lab.scale if lab is not None else None, lab.bias if lab is not None else None, addend,
+                training=self.training, momentum=norm.momentum, eps=norm.eps)
+        x = norm(x)
+        if addend is not None:
+            x = x + addend
+        if act_name is not None:
+            x = _ACTS[act_name](x)
+        if lab is not None:
+            x = lab(x)
         return x
+
+    def _flush_batch_counter(self, *args):
+        # nn.BatchNorm2d counts forward calls in ``num_batches_tracked``; the fused path counts on the
+        # host and writes the buffer only when a state_dict is taken (no per-layer launch per step)
+        norm = getattr(self, self.norm_name)
+        if self._pending_batches and getattr(norm, "num_batches_tracked", None) is not None:
+            norm.num_batches_tracked += self._pending_batches
+        self._pending_batches = 0
 
 
 class MLP(nn.Module):

@@ -211,3 +211,85 @@ def depthwise_conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1) -> 
     if x.dtype not in (torch.float32, torch.bfloat16):
         x = x.float()
     return _DepthwiseConv2d.apply(x, weight, int(stride))
+
+
+_ACT_CODES = {None: 0, "relu": 1, "silu": 2}
+
+
+def _nhwc(t):
+    v = t.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+class _BatchNormAct(torch.autograd.Function):
+    """Training-mode BN + addend + activation + LAB; see include/dfine_hip.h (dfine_bn_act_*)."""
+
+    @staticmethod
+    def forward(ctx, x, addend, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, eps, momentum, training):
+        _lib.require_gpu(x, gamma, beta)
+        lib = _lib.load()
+        B, C, H, W = x.shape
+        xl = _nhwc(x)
+        al = _nhwc(addend.to(x.dtype)) if addend is not None else None
+        n_pix = B * H * W
+        y = torch.empty_like(xl)
+        # one zeroed workspace: fp64 sums [2C] (as 4C floats) | save_mean [C] | save_rstd [C]
+        ws = torch.zeros(6 * C, dtype=torch.float32, device=x.device)
+        sums, save_mean, save_rstd = ws[: 4 * C], ws[4 * C : 5 * C], ws[5 * C :]
+        g32, b32 = gamma.detach().float(), beta.detach().float()
+        ls32 = lab_scale.detach().float() if lab_scale is not None else None
+        lb32 = lab_bias.detach().float() if lab_bias is not None else None
+        nbytes = (2 * xl.numel() + y.numel() + (al.numel() if al is not None else 0)) * xl.element_size()
+        with _lib.timed("bn_act_fwd", nbytes):
+            rc = lib.dfine_bn_act_fwd(_lib.ptr(xl), _lib.ptr(al), _lib.ptr(y), _lib.dtype_code(xl), _lib.ptr(sums),
+                                      _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(running_mean), _lib.ptr(running_var),
+                                      _lib.ptr(save_mean), _lib.ptr(save_rstd), _lib.ptr(ls32), _lib.ptr(lb32), n_pix, C,
+                                      _ACT_CODES[act], int(training), eps, momentum, _lib.stream_ptr())
+        _lib.check(rc, "dfine_bn_act_fwd")
+        ctx.save_for_backward(xl, al, g32, b32, save_mean, save_rstd, ls32)
+        ctx.cfg = (act, eps, int(training), gamma.dtype, lab_scale.dtype if lab_scale is not None else None)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        xl, al, g32, b32, save_mean, save_rstd, ls32 = ctx.saved_tensors
+        act, eps, training, g_dtype, lab_dtype = ctx.cfg
+        if not training:
+            raise _lib.DfineHipError("fused BatchNorm backward is only built for batch statistics (training mode)")
+        lib = _lib.load()
+        n_pix, C = xl.numel() // xl.shape[-1], xl.shape[-1]
+        gy = _nhwc(grad_y.to(xl.dtype))
+        dx = torch.empty_like(xl)
+        dadd = torch.empty_like(xl) if al is not None else None
+        # one zeroed workspace: fp64 reductions [4C] (as 8C floats) | dgamma [C] | dbeta [C] | dlab [2]
+        ws = torch.zeros(10 * C + 2, dtype=torch.float32, device=xl.device)
+        red, dgamma, dbeta, dlab = ws[: 8 * C], ws[8 * C : 9 * C], ws[9 * C : 10 * C], ws[10 * C :]
+        nbytes = (2 * xl.numel() + 3 * gy.numel() + (2 * al.numel() if al is not None else 0)) * xl.element_size()
+        with _lib.timed("bn_act_bwd", nbytes):
+            rc = lib.dfine_bn_act_bwd(_lib.ptr(xl), _lib.ptr(al), _lib.ptr(gy), _lib.dtype_code(xl), _lib.ptr(save_mean),
+                                      _lib.ptr(save_rstd), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(ls32), _lib.ptr(red),
+                                      _lib.ptr(dx), _lib.ptr(dadd), _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                      _lib.ptr(dlab) if ls32 is not None else None, n_pix, C, _ACT_CODES[act],
+                                      training, eps, _lib.stream_ptr())
+        _lib.check(rc, "dfine_bn_act_bwd")
+        return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None,
+                dgamma.to(g_dtype), dbeta.to(g_dtype), None, None,
+                dlab[0:1].to(lab_dtype) if ls32 is not None else None,
+                dlab[1:2].to(lab_dtype) if ls32 is not None else None, None, None, None, None)
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, lab_scale=None, lab_bias=None,
+                   addend=None, training=True, momentum=0.1, eps=1e-5):
+    """Fused ``lab_scale * act(batch_norm(x) + addend) + lab_bias`` on a channels_last map
+    (float32 or bfloat16). ``lab_scale`` / ``lab_bias`` are float tensors [1] (both or neither);
+    ``act`` is None, "relu" or "silu". In training mode the running statistics are updated in place exactly like
+    nn.BatchNorm2d (momentum, unbiased variance)."""
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    return _BatchNormAct.apply(x, addend, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, float(eps),
+                               float(momentum), bool(training))
+
+
+def batch_norm_act_supported(x, channels):
+    """The fused kernels need 16-byte channel vectors: C % 8 == 0 for bf16, C % 4 == 0 for f32."""
+    return x.is_cuda and channels % (8 if x.dtype == torch.bfloat16 else 4) == 0

@@ -128,6 +128,32 @@ int dfine_dwconv_bwd_data(const void* dy, const float* w, void* dx, int dtype, i
 int dfine_dwconv_bwd_weight(const void* x, const void* dy, float* dw, int dtype, int B, int H, int W,
                             int C, int k, int stride, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Fused BatchNorm2d (batch statistics) [+ addend] + activation [+ learnable affine], channel-last:
+ *     z = (x - mean_c) * rstd_c * gamma_c + beta_c (+ addend);   y = lab_scale * act(z) + lab_bias
+ * Replaces the norm -> act -> lab tail of ConvBNAct (src/d_fine/arch/hgnetv2.py:66-80),
+ * ConvNormLayer(_fuse).forward (hybrid_encoder.py:39-45, 92-93) and the sum + activation of
+ * VGGBlock.forward (hybrid_encoder.py:115-121; `addend` = the other branch), forward and backward.
+ *
+ *   x, addend, y, dy, dx, dadd   [n_pix, C] (= [B,H,W,C]) bf16 or f32 (dtype); addend/dadd/lab_* may be NULL
+ *   gamma, beta, running_mean, running_var, save_mean, save_rstd, dgamma, dbeta   f32 [C]
+ *   lab_scale, lab_bias  f32 [1] each on the device (both or neither);  dlab f32 [2] =
+ *       (d scale, d bias), ACCUMULATED (caller zeroes)
+ *   sums f64 [2*C], red f64 [4*C]: workspaces, ZEROED by the caller before the call
+ *   act: 0 identity, 1 ReLU, 2 SiLU.  training=1: batch statistics, running stats updated
+ *   (momentum, unbiased variance); training=0 (forward only): running statistics.
+ * Supported: C % 8 == 0 (bf16) / C % 4 == 0 (f32).
+ * ------------------------------------------------------------------------------------- */
+int dfine_bn_act_fwd(const void* x, const void* addend, void* y, int dtype, double* sums,
+                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     float* save_mean, float* save_rstd, const float* lab_scale, const float* lab_bias,
+                     int n_pix, int C, int act, int training, float eps, float momentum, void* stream);
+int dfine_bn_act_bwd(const void* x, const void* addend, const void* dy, int dtype,
+                     const float* save_mean, const float* save_rstd, const float* gamma,
+                     const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
+                     float* dgamma, float* dbeta, float* dlab, int n_pix, int C, int act, int training,
+                     float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

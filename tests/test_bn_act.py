@@ -1,0 +1,83 @@
+"""Fused BatchNorm(+addend)+activation(+LAB) HIP kernels against a plain PyTorch fp32 reference
+(F.batch_norm in training mode -> act -> scale*x+bias on the CPU), forward, all gradients and the
+running-statistics update."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ACTS = {None: lambda t: t, "relu": F.relu, "silu": F.silu}
+
+
+def _reference(x, addend, gamma, beta, rm, rv, act, lab_scale, lab_bias):
+    z = F.batch_norm(x, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    if addend is not None:
+        z = z + addend
+    y = ACTS[act](z)
+    if lab_scale is not None:
+        y = lab_scale * y + lab_bias
+    return y
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 32, 160, 160), (3, 96, 20, 20), (2, 1536, 5, 5), (1, 8, 3, 7), (4, 256, 40, 40)])
+@pytest.mark.parametrize("act,with_lab,with_add", [("relu", True, False), ("silu", False, False), (None, False, False), ("silu", False, True), ("relu", True, True)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_act_matches_torch_fp32(hip_lib, B, C, H, W, act, with_lab, with_add, dtype):
+    from dfine_seg_amd import ops
+
+    g = torch.Generator().manual_seed(C + H)
+    # mean far from 0 on purpose: the statistics must survive |mean| >> std
+    x = (torch.randn(B, C, H, W, generator=g) * 0.5 + 3.0).to(dtype)
+    addend = torch.randn(B, C, H, W, generator=g).to(dtype) if with_add else None
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    ls, lb = (torch.tensor([1.1]), torch.tensor([-0.2])) if with_lab else (None, None)
+    gy = torch.randn(B, C, H, W, generator=g).to(dtype)
+
+    leaf = lambda t: t.float().clone().requires_grad_(True) if t is not None else None
+    xr, ar, gr, br, lsr, lbr = leaf(x), leaf(addend), leaf(gamma), leaf(beta), leaf(ls), leaf(lb)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y_ref = _reference(xr, ar, gr, br, rm_ref, rv_ref, act, lsr, lbr)
+    y_ref.backward(gy.float())
+
+    dev = lambda t: t.cuda().requires_grad_(True) if t is not None else None
+    cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True) if t is not None else None
+    xd, ad, gd, bd, lsd, lbd = cl(x), cl(addend), dev(gamma), dev(beta), dev(ls), dev(lb)
+    rm_d, rv_d = rm.cuda(), rv.cuda()
+    y = ops.batch_norm_act(xd, gd, bd, rm_d, rv_d, act, lsd, lbd, ad, training=True)
+    assert y.dtype == dtype and y.shape == y_ref.shape
+    y.backward(gy.cuda())
+
+    if dtype == torch.float32:
+        tol = dict(rtol=2e-4, atol=2e-4)
+    else:  # one bf16 rounding of y / dx (rel 2^-9) on O(1..4) values
+        tol = dict(rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(y.float().cpu(), y_ref.detach(), **tol)
+    torch.testing.assert_close(rm_d.cpu(), rm_ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rv_d.cpu(), rv_ref, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(xd.grad.float().cpu(), xr.grad, **tol)
+    if with_add:
+        torch.testing.assert_close(ad.grad.float().cpu(), ar.grad, **tol)
+    n = B * H * W
+    red_tol = dict(rtol=5e-3, atol=(2e-5 if dtype == torch.float32 else 2e-3) * n**0.5 + 1e-4)
+    torch.testing.assert_close(gd.grad.cpu(), gr.grad, **red_tol)
+    torch.testing.assert_close(bd.grad.cpu(), br.grad, **red_tol)
+    if with_lab:
+        lab_tol = dict(rtol=5e-3, atol=(2e-5 if dtype == torch.float32 else 2e-3) * (n * C) ** 0.5 + 1e-3)
+        torch.testing.assert_close(lsd.grad.cpu(), lsr.grad, **lab_tol)
+        torch.testing.assert_close(lbd.grad.cpu(), lbr.grad, **lab_tol)
+
+
+def test_eval_mode_uses_running_statistics(hip_lib):
+    from dfine_seg_amd import ops
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 64, 9, 9, generator=g)
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    rm, rv = torch.randn(64, generator=g), torch.rand(64, generator=g) + 0.5
+    ref = F.silu(F.batch_norm(x, rm, rv, gamma, beta, training=False, eps=1e-5))
+    with torch.no_grad():
+        y = ops.batch_norm_act(x.cuda().contiguous(memory_format=torch.channels_last), gamma.cuda(), beta.cuda(),
+                               rm.cuda(), rv.cuda(), "silu", training=False)
+    torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-4)
