@@ -70,6 +70,36 @@ struct VecTraits<bf16_t> {
   __device__ static __forceinline__ float load1(const bf16_t* p) { return bf16_to_f32(*p); }
 };
 
+// VEC consecutive elements of T <-> fp32, as ONE naturally aligned access of VEC*sizeof(T) bytes
+// (16, 8, 4 or 2 bytes), for maps whose channel count is not a multiple of the 16-byte vector.
+template <int BYTES>
+struct RawBytes;
+template <> struct RawBytes<16> { typedef uint4 type; };
+template <> struct RawBytes<8> { typedef uint2 type; };
+template <> struct RawBytes<4> { typedef uint32_t type; };
+template <> struct RawBytes<2> { typedef uint16_t type; };
+
+template <typename T, int VEC>
+__device__ __forceinline__ void load_vec(const T* p, float* f) {
+  typedef typename RawBytes<VEC * sizeof(T)>::type raw_t;
+  union { raw_t raw; T e[VEC]; } u;
+  u.raw = *reinterpret_cast<const raw_t*>(p);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) f[i] = VecTraits<T>::load1(&u.e[i]);
+}
+
+__device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store1(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+template <typename T, int VEC>
+__device__ __forceinline__ void store_vec(T* p, const float* f) {
+  typedef typename RawBytes<VEC * sizeof(T)>::type raw_t;
+  union { raw_t raw; T e[VEC]; } u;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) store1(&u.e[i], f[i]);
+  *reinterpret_cast<raw_t*>(p) = u.raw;
+}
+
 // Sum over aligned groups of WIDTH lanes (WIDTH a power of two <= 64); every lane of the
 // group ends with the group's sum.
 template <int WIDTH>

@@ -65,9 +65,8 @@ struct ColReduce {
   }
 };
 
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, double* __restrict__ sums, NaGeom g) {
-  constexpr int VEC = VecTraits<T>::kElems;
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int c0 = (blockIdx.y * blockDim.x + threadIdx.x) * VEC;
   float acc[2][VEC];
@@ -78,7 +77,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
     const int pix = first + n * blockDim.y;
     if (pix >= g.n_pix) break;
     float v[VEC];
-    VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(x + (size_t)pix * g.C + c0), v);
+    load_vec<T, VEC>(x + (size_t)pix * g.C + c0, v);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       acc[0][i] += v[i];
@@ -106,13 +105,12 @@ __device__ __forceinline__ void channel_stats(const double* sums, const float* r
   }
 }
 
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const T* __restrict__ x, const T* __restrict__ addend, T* __restrict__ y,
     const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ save_mean,
     float* __restrict__ save_rstd, const float* __restrict__ lab_scale, const float* __restrict__ lab_bias, NaGeom g) {
-  constexpr int VEC = VecTraits<T>::kElems;
   const int c0 = (blockIdx.y * blockDim.x + threadIdx.x) * VEC;
   float scale[VEC], shift[VEC];
 #pragma unroll
@@ -136,26 +134,25 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     if (pix >= g.n_pix) break;
     const size_t off = (size_t)pix * g.C + c0;
     float v[VEC], a[VEC];
-    VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(x + off), v);
-    if (g.has_add) VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(addend + off), a);
+    load_vec<T, VEC>(x + off, v);
+    if (g.has_add) load_vec<T, VEC>(addend + off, a);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       float z = v[i] * scale[i] + shift[i];
       if (g.has_add) z += a[i];
       v[i] = ls * act_fwd(z, g.act) + lb;
     }
-    *reinterpret_cast<Vec16*>(y + off) = VecTraits<T>::pack(v);
+    store_vec<T, VEC>(y + off, v);
   }
 }
 
 // Backward pass 1: per channel sum(dz), sum(dz * xhat), sum(dy * act(z)) [-> d lab_scale], sum(dy) [-> d lab_bias]
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const T* __restrict__ x, const T* __restrict__ addend, const T* __restrict__ dy,
     const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ lab_scale,
     double* __restrict__ red_out, NaGeom g) {
-  constexpr int VEC = VecTraits<T>::kElems;
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int c0 = (blockIdx.y * blockDim.x + threadIdx.x) * VEC;
   float mean[VEC], rstd[VEC], gam[VEC], bet[VEC];
@@ -178,9 +175,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     if (pix >= g.n_pix) break;
     const size_t off = (size_t)pix * g.C + c0;
     float v[VEC], a[VEC], d[VEC];
-    VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(x + off), v);
-    VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(dy + off), d);
-    if (g.has_add) VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(addend + off), a);
+    load_vec<T, VEC>(x + off, v);
+    load_vec<T, VEC>(dy + off, d);
+    if (g.has_add) load_vec<T, VEC>(addend + off, a);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const float xhat = (v[i] - mean[i]) * rstd[i];
@@ -198,14 +195,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 
 // Backward pass 2: dx = gamma*rstd * (dz - mean(dz) - xhat*mean(dz*xhat)); dadd = dz;
 // block row 0 also publishes dgamma/dbeta (fp32) and adds its channels' share of d lab.
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
     const T* __restrict__ x, const T* __restrict__ addend, const T* __restrict__ dy,
     const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ lab_scale,
     const double* __restrict__ red_in, T* __restrict__ dx, T* __restrict__ dadd,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dlab, NaGeom g) {
-  constexpr int VEC = VecTraits<T>::kElems;
   const int c0 = (blockIdx.y * blockDim.x + threadIdx.x) * VEC;
   float mean[VEC], rstd[VEC], gam[VEC], bet[VEC], m_dz[VEC], m_dzx[VEC];
   float lab_s = 0.f, lab_b = 0.f;
@@ -238,9 +234,9 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
     if (pix >= g.n_pix) break;
     const size_t off = (size_t)pix * g.C + c0;
     float v[VEC], a[VEC], d[VEC];
-    VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(x + off), v);
-    VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(dy + off), d);
-    if (g.has_add) VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(addend + off), a);
+    load_vec<T, VEC>(x + off, v);
+    load_vec<T, VEC>(dy + off, d);
+    if (g.has_add) load_vec<T, VEC>(addend + off, a);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       const float xhat = (v[i] - mean[i]) * rstd[i];
@@ -250,8 +246,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
       a[i] = dz;
       v[i] = gam[i] * rstd[i] * (dz - m_dz[i] - xhat * m_dzx[i]);
     }
-    *reinterpret_cast<Vec16*>(dx + off) = VecTraits<T>::pack(v);
-    if (g.has_add) *reinterpret_cast<Vec16*>(dadd + off) = VecTraits<T>::pack(a);
+    store_vec<T, VEC>(dx + off, v);
+    if (g.has_add) store_vec<T, VEC>(dadd + off, a);
   }
 }
 
@@ -260,9 +256,8 @@ struct NaLaunch {
   int ppt;
 };
 
-template <typename T>
+template <int VEC>
 static int plan(NaLaunch* L, int n_pix, int C, int target_blocks) {
-  constexpr int VEC = VecTraits<T>::kElems;
   if (C % VEC != 0) return DFINE_E_UNSUPPORTED;
   int cgb = 1;
   for (int d = 32; d >= 1; --d)
@@ -286,47 +281,62 @@ static NaGeom make_geom(int n_pix, int C, int ppt, int act, bool has_add, bool h
   return g;
 }
 
-template <typename T>
+template <typename T, int VEC>
 static int fwd_impl(const void* x, const void* addend, void* y, double* sums, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float* save_mean, float* save_rstd, const float* lab_scale,
                     const float* lab_bias, int n_pix, int C, int act, int training, float eps, float momentum, hipStream_t st) {
-  constexpr int VEC = VecTraits<T>::kElems;
   NaLaunch R, A;
-  if (int rc = plan<T>(&R, n_pix, C, 512)) return rc;   // reductions: few blocks -> few contended atomics
-  if (int rc = plan<T>(&A, n_pix, C, 2048)) return rc;  // streaming: fill the chip
+  if (int rc = plan<VEC>(&R, n_pix, C, 512)) return rc;   // reductions: few blocks -> few contended atomics
+  if (int rc = plan<VEC>(&A, n_pix, C, 2048)) return rc;  // streaming: fill the chip
   if (training) {
     NaGeom g = make_geom(n_pix, C, R.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, momentum);
     const size_t lds = (size_t)R.block.y * 2 * R.block.x * VEC * sizeof(float);
-    hipLaunchKernelGGL(bn_stats_kernel<T>, R.grid, R.block, lds, st, (const T*)x, sums, g);
+    hipLaunchKernelGGL((bn_stats_kernel<T, VEC>), R.grid, R.block, lds, st, (const T*)x, sums, g);
     DFINE_LAUNCH_CHECK();
   }
   NaGeom g = make_geom(n_pix, C, A.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, momentum);
-  hipLaunchKernelGGL(bn_apply_kernel<T>, A.grid, A.block, 0, st, (const T*)x, (const T*)addend, (T*)y, sums, gamma, beta,
+  hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), A.grid, A.block, 0, st, (const T*)x, (const T*)addend, (T*)y, sums, gamma, beta,
                      running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, g);
   DFINE_LAUNCH_CHECK();
   return 0;
 }
 
-template <typename T>
+template <typename T, int VEC>
 static int bwd_impl(const void* x, const void* addend, const void* dy, const float* save_mean, const float* save_rstd,
                     const float* gamma, const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
                     float* dgamma, float* dbeta, float* dlab, int n_pix, int C, int act, int training, float eps,
                     hipStream_t st) {
-  constexpr int VEC = VecTraits<T>::kElems;
   NaLaunch R, A;
-  if (int rc = plan<T>(&R, n_pix, C, 512)) return rc;
-  if (int rc = plan<T>(&A, n_pix, C, 2048)) return rc;
+  if (int rc = plan<VEC>(&R, n_pix, C, 512)) return rc;
+  if (int rc = plan<VEC>(&A, n_pix, C, 2048)) return rc;
   NaGeom g = make_geom(n_pix, C, R.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, 0.f);
   const size_t lds = (size_t)R.block.y * 4 * R.block.x * VEC * sizeof(float);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy,
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy,
                      save_mean, save_rstd, gamma, beta, lab_scale, red, g);
   DFINE_LAUNCH_CHECK();
   g.pix_per_thread = A.ppt;
-  hipLaunchKernelGGL(bn_bwd_dx_kernel<T>, A.grid, A.block, 0, st, (const T*)x, (const T*)addend, (const T*)dy, save_mean,
+  hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VEC>), A.grid, A.block, 0, st, (const T*)x, (const T*)addend, (const T*)dy, save_mean,
                      save_rstd, gamma, beta, lab_scale, red, (T*)dx, (T*)dadd, dgamma, dbeta, dlab, g);
   DFINE_LAUNCH_CHECK();
   return 0;
 }
+
+// widest channel vector (<= 16 bytes) that divides C: any channel count works, wide ones stream
+#define DFINE_NA_DISPATCH(CALL)                      \
+  do {                                               \
+    if (dtype == DFINE_DT_BF16) {                    \
+      if (C % 8 == 0) return CALL(bf16_t, 8);        \
+      if (C % 4 == 0) return CALL(bf16_t, 4);        \
+      if (C % 2 == 0) return CALL(bf16_t, 2);        \
+      return CALL(bf16_t, 1);                        \
+    }                                                \
+    if (dtype == DFINE_DT_F32) {                     \
+      if (C % 4 == 0) return CALL(float, 4);         \
+      if (C % 2 == 0) return CALL(float, 2);         \
+      return CALL(float, 1);                         \
+    }                                                \
+    return DFINE_E_UNSUPPORTED;                      \
+  } while (0)
 
 }  // namespace dfine
 
@@ -342,11 +352,9 @@ extern "C" int dfine_bn_act_fwd(const void* x, const void* addend, void* y, int 
   if (n_pix <= 0 || C <= 0 || act < 0 || act > 2) return DFINE_E_BADARG;
   if ((lab_scale != nullptr) != (lab_bias != nullptr)) return DFINE_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DFINE_DT_BF16)
-    return fwd_impl<bf16_t>(x, addend, y, sums, gamma, beta, running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, n_pix, C, act, training, eps, momentum, st);
-  if (dtype == DFINE_DT_F32)
-    return fwd_impl<float>(x, addend, y, sums, gamma, beta, running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, n_pix, C, act, training, eps, momentum, st);
-  return DFINE_E_UNSUPPORTED;
+#define FWD(T, V) fwd_impl<T, V>(x, addend, y, sums, gamma, beta, running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, n_pix, C, act, training, eps, momentum, st)
+  DFINE_NA_DISPATCH(FWD);
+#undef FWD
 }
 
 extern "C" int dfine_bn_act_bwd(const void* x, const void* addend, const void* dy, int dtype,
@@ -359,9 +367,7 @@ extern "C" int dfine_bn_act_bwd(const void* x, const void* addend, const void* d
   if (lab_scale && !dlab) return DFINE_E_BADARG;
   if (n_pix <= 0 || C <= 0 || act < 0 || act > 2) return DFINE_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == DFINE_DT_BF16)
-    return bwd_impl<bf16_t>(x, addend, dy, save_mean, save_rstd, gamma, beta, lab_scale, red, dx, dadd, dgamma, dbeta, dlab, n_pix, C, act, training, eps, st);
-  if (dtype == DFINE_DT_F32)
-    return bwd_impl<float>(x, addend, dy, save_mean, save_rstd, gamma, beta, lab_scale, red, dx, dadd, dgamma, dbeta, dlab, n_pix, C, act, training, eps, st);
-  return DFINE_E_UNSUPPORTED;
+#define BWD(T, V) bwd_impl<T, V>(x, addend, dy, save_mean, save_rstd, gamma, beta, lab_scale, red, dx, dadd, dgamma, dbeta, dlab, n_pix, C, act, training, eps, st)
+  DFINE_NA_DISPATCH(BWD);
+#undef BWD
 }

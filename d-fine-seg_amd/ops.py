@@ -291,5 +291,5 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, lab_scal
 
 
 def batch_norm_act_supported(x, channels):
-    """The fused kernels need 16-byte channel vectors: C % 8 == 0 for bf16, C % 4 == 0 for f32."""
-    return x.is_cuda and channels % (8 if x.dtype == torch.bfloat16 else 4) == 0
+    """Any channel count (narrow vectors for odd counts, e.g. D-FINE-n's 21-channel CSP branch)."""
+    return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)

@@ -142,7 +142,7 @@ int dfine_dwconv_bwd_weight(const void* x, const void* dy, float* dw, int dtype,
  *   sums f64 [2*C], red f64 [4*C]: workspaces, ZEROED by the caller before the call
  *   act: 0 identity, 1 ReLU, 2 SiLU.  training=1: batch statistics, running stats updated
  *   (momentum, unbiased variance); training=0 (forward only): running statistics.
- * Supported: C % 8 == 0 (bf16) / C % 4 == 0 (f32).
+ * Any C (the widest channel vector <= 16 bytes that divides C is used).
  * ------------------------------------------------------------------------------------- */
 int dfine_bn_act_fwd(const void* x, const void* addend, void* y, int dtype, double* sums,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,

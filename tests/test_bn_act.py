@@ -20,7 +20,7 @@ def _reference(x, addend, gamma, beta, rm, rv, act, lab_scale, lab_bias):
     return y
 
 
-@pytest.mark.parametrize("B,C,H,W", [(2, 32, 160, 160), (3, 96, 20, 20), (2, 1536, 5, 5), (1, 8, 3, 7), (4, 256, 40, 40)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 32, 160, 160), (3, 96, 20, 20), (2, 1536, 5, 5), (1, 8, 3, 7), (4, 256, 40, 40), (2, 21, 20, 20), (2, 12, 33, 31), (2, 42, 10, 10)])
 @pytest.mark.parametrize("act,with_lab,with_add", [("relu", True, False), ("silu", False, False), (None, False, False), ("silu", False, True), ("relu", True, True)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_bn_act_matches_torch_fp32(hip_lib, B, C, H, W, act, with_lab, with_add, dtype):

@@ -111,7 +111,7 @@ def test_reducer_rccl_single_rank_train_step(hip_lib):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        trainer = TrainStep("n", 80, False, (320, 320), "cuda", grad_reducer=BucketedGradReducer, total_steps=10)
+        trainer = TrainStep("n", 80, False, (320, 320), "cuda", grad_reducer=BucketedGradReducer, total_steps=100)
         images, targets = synthetic_batch(2, 320, 320, 80, 4, seed=1, device="cuda")
         for _ in range(2):
             loss = trainer.step(images, targets)
