@@ -183,7 +183,7 @@ class DFINECriterion(nn.Module):
             spec.cost_class, spec.cost_bbox, spec.cost_giou)
         go = ops.go_union(gt_of_query)
         # ---- normalisers: one 2-float all-reduce (dfine_criterion.py:436-453 issues two)
-        norm = torch.stack([(go >= 0).sum().float(), torch.tensor(float(tb.total), device=dev)])
+        norm = torch.stack([(go >= 0).sum().float(), tb.counts.sum().float()])
         world = 1
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(norm)

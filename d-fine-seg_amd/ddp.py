@@ -2,11 +2,10 @@
 replacing the reference's ``DistributedDataParallel`` wrap (src/dl/train.py:157-169, collectives
 C1-C3 in SURVEY.md 2.3).
 
-  * gradients live in a few large flat fp32 buckets (``p.grad`` are views into them), filled in
-    reverse registration order -- decoder, encoder, backbone -- which is the order backward produces
-    them;
-  * when the last gradient of a bucket has been accumulated, the bucket is all-reduced (mean) on a
-    side HIP stream, overlapping the rest of backward; ``finish()`` joins before clip/optimizer;
+  * gradients live in ONE flat fp32 buffer (``optim.FlatState``: ``p.grad`` are views into it, laid
+    out in the order backward produces them); a bucket is a contiguous range of that buffer;
+  * when the last gradient of a bucket has been accumulated, the range is all-reduced (mean) on a
+    side HIP stream, overlapping the rest of backward; ``finish()`` joins before the optimizer;
   * xGMI is point-to-point (7 links per GPU): few large messages beat DDP's 25 MB default, so the
     default is 4 buckets for D-FINE-m's 78 MB of gradients;
   * parameters that received no gradient this step (e.g. the denoising embedding on a batch with no
@@ -15,15 +14,17 @@ C1-C3 in SURVEY.md 2.3).
   * parameters are broadcast from rank 0 once; BatchNorm statistics stay per-rank (DDP re-broadcasts
     all buffers every forward, C3).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+from .optim import FlatState
 
 
 def init_distributed():
     """Process group from the torchrun environment (reference dist_utils.py:12-43): RCCL when a
     GPU is present, Gloo otherwise. Returns (rank, world_size, local_rank)."""
-    import os
-
     if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
         return 0, 1, 0
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", 0))
@@ -36,16 +37,15 @@ def init_distributed():
     return rank, world, local
 
 
-def assign_buckets(named_params, num_buckets=4, min_bucket_bytes=1 << 20):
-    """Split trainable parameters, LAST registered first, into ``num_buckets`` contiguous groups of
-    roughly equal byte size. Returns a list of lists of (name, param)."""
-    params = [(n, p) for n, p in named_params if p.requires_grad][::-1]
-    total = sum(p.numel() * 4 for _, p in params)
+def assign_buckets(entries, num_buckets=4, min_bucket_bytes=1 << 20):
+    """Cut the flat layout (``FlatState.entries``: (name, param, offset, numel, group)) into at most
+    ``num_buckets`` contiguous runs of roughly equal byte size. Returns lists of entries."""
+    total = sum(e[3] * 4 for e in entries)
     target = max(total / max(num_buckets, 1), min_bucket_bytes)
     buckets, cur, cur_bytes = [], [], 0
-    for n, p in params:
-        cur.append((n, p))
-        cur_bytes += p.numel() * 4
+    for e in entries:
+        cur.append(e)
+        cur_bytes += e[3] * 4
         if cur_bytes >= target and len(buckets) < num_buckets - 1:
             buckets.append(cur)
             cur, cur_bytes = [], 0
@@ -55,38 +55,40 @@ def assign_buckets(named_params, num_buckets=4, min_bucket_bytes=1 << 20):
 
 
 class _Bucket:
-    def __init__(self, params, device):
-        self.params = params
-        self.flat = torch.zeros(sum(p.numel() for _, p in params), dtype=torch.float32, device=device)
-        offset = 0
-        for _, p in params:
-            p.grad = self.flat[offset : offset + p.numel()].view_as(p)  # autograd accumulates in place
-            offset += p.numel()
-        self.pending = len(params)
+    def __init__(self, entries, flat_grads):
+        self.params = [e[1] for e in entries]
+        begin = entries[0][2]
+        end = entries[-1][2] + entries[-1][3]
+        self.flat = flat_grads[begin:end]  # padding between optimizer groups is zero and stays zero
+        self.pending = len(self.params)
         self.work = None
 
 
 class BucketedGradReducer:
-    """``reducer = BucketedGradReducer(model)`` before training; per step: backward (hooks fire),
-    ``reducer.finish()``, optimizer, ``reducer.zero_grad()``."""
+    """``reducer = BucketedGradReducer(model_or_flat_state)`` before training; per step: backward (hooks
+    fire), ``reducer.finish()``, optimizer (which zeroes the flat gradients) or ``reducer.zero_grad()``."""
 
     def __init__(self, model, num_buckets=4, process_group=None, broadcast_parameters=True):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("BucketedGradReducer needs an initialised process group")
         self.group = process_group
         self.world = dist.get_world_size(process_group)
-        device = next(model.parameters()).device
+        self.flat = model if isinstance(model, FlatState) else FlatState(model)
+        tensors = [self.flat.params]
+        if not isinstance(model, FlatState):
+            tensors += [b for b in model.buffers()] + [p for p in model.parameters() if not p.requires_grad]
+        device = self.flat.device
         self.on_gpu = device.type == "cuda"
         self.side_stream = torch.cuda.Stream(device) if self.on_gpu else None
         self.backend_has_avg = dist.get_backend(process_group) == "nccl"
-        if broadcast_parameters:  # C2: everyone starts from rank 0's weights (buffers included, once)
+        if broadcast_parameters:  # C2: everyone starts from rank 0's weights (one flat message)
             with torch.no_grad():
-                for t in list(model.parameters()) + list(model.buffers()):
+                for t in tensors:
                     dist.broadcast(t, src=0, group=process_group)
-        self.buckets = [_Bucket(b, device) for b in assign_buckets(model.named_parameters(), num_buckets)]
+        self.buckets = [_Bucket(b, self.flat.grads) for b in assign_buckets(self.flat.entries, num_buckets)]
         self._owner = {}
         for b in self.buckets:
-            for _, p in b.params:
+            for p in b.params:
                 self._owner[p] = b
                 p.register_post_accumulate_grad_hook(self._on_grad_ready)
 
@@ -131,5 +133,4 @@ class BucketedGradReducer:
             b.work, b.pending = None, len(b.params)
 
     def zero_grad(self):
-        for b in self.buckets:
-            b.flat.zero_()
+        self.flat.grads.zero_()

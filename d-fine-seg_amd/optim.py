@@ -1,0 +1,167 @@
+"""Flat parameter/gradient storage and the fused optimizer tail (HIP, csrc/optim.hip).
+
+``FlatState`` re-homes every trainable parameter of a model into ONE fp32 buffer (and its
+gradient into another), ordered by optimizer group; the parameters stay ordinary ``nn.Parameter``
+views (same shapes, strides and ``state_dict``), so nothing else changes. On top of it:
+
+  * ``FusedAdamWEMA.step()`` = global-norm clip + AdamW (the reference's four groups) + EMA +
+    gradient zeroing in two kernel launches, with all per-step scalars read from a small device
+    array (one async H2D copy per step) -- the launch sequence never changes, so the step can be
+    captured in a hipGraph;
+  * ``ddp.BucketedGradReducer`` uses contiguous ranges of the flat gradient buffer as its buckets.
+"""
+import math
+
+import torch
+
+from . import _lib
+
+_HYPER_LEN = 24
+_GROUP_OFF = 8
+
+
+def group_parameters(model):
+    """The reference's four AdamW groups (src/d_fine/dfine.py:87-124) as lists of (name, param)."""
+    groups = {"backbone": [], "backbone_norm": [], "encdec_norm_bias": [], "rest": []}
+    for name, p in model.named_parameters():
+        is_norm = "norm" in name or "bn" in name
+        if "backbone" in name:
+            groups["backbone_norm" if is_norm else "backbone"].append((name, p))
+        elif ("encoder" in name or "decoder" in name) and (is_norm or "bias" in name):
+            groups["encdec_norm_bias"].append((name, p))
+        else:
+            groups["rest"].append((name, p))
+    return groups
+
+
+class FlatState:
+    """Flat fp32 homes for the trainable parameters and their gradients.
+
+    Order: group by group (``group_order``), and inside a group LAST registered first, so that a
+    contiguous range of the buffer fills up in the order backward produces gradients."""
+
+    def __init__(self, model, group_order=("rest", "encdec_norm_bias", "backbone", "backbone_norm")):
+        groups = group_parameters(model)
+        self.group_names = list(group_order)
+        self.entries = []  # (name, param, offset, numel, group index)
+        self.group_begin = []
+        offset = 0
+        for gi, gname in enumerate(group_order):
+            self.group_begin.append(offset)
+            for name, p in reversed(groups[gname]):
+                if not p.requires_grad:
+                    continue
+                if p.dtype != torch.float32:
+                    raise TypeError(f"{name}: fused optimizer expects fp32 master weights, got {p.dtype}")
+                self.entries.append((name, p, offset, p.numel(), gi))
+                offset += p.numel()
+            offset = (offset + 3) // 4 * 4  # keep every group 16-byte aligned
+        self.numel = offset
+        device = self.entries[0][1].device
+        self.device = device
+        self.params = torch.zeros(offset, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(offset, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for name, p, off, n, _ in self.entries:
+                home = self.view_like(self.params, p, off)
+                home.copy_(p.data)
+                p.data = home
+                p.grad = self.view_like(self.grads, p, off)
+
+    @staticmethod
+    def view_like(flat, p, offset):
+        """A view of ``flat`` with p's shape AND strides (channels_last conv weights stay channels_last)."""
+        return flat[offset : offset + p.numel()].as_strided(p.size(), p.stride())
+
+    def mirror(self, other_model):
+        """Flat buffer holding ``other_model``'s copies of the same parameters, in the same order
+        (used for the EMA model). Its parameters become views of the returned buffer."""
+        theirs = dict(other_model.named_parameters())
+        flat = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        with torch.no_grad():
+            for name, p, off, n, _ in self.entries:
+                q = theirs[name]
+                home = self.view_like(flat, q, off)
+                home.copy_(q.data)
+                q.data = home
+        return flat
+
+
+class FusedAdamWEMA:
+    """clip_grad_norm_ + AdamW + zero_grad (+ EMA of the weights) over a FlatState.
+
+    ``lrs`` / ``weight_decays``: dicts by group name. ``set_schedule(lrs, ema_decay)`` before each
+    ``step()`` refreshes the device-side scalars."""
+
+    def __init__(self, flat: FlatState, lrs, weight_decays, betas=(0.9, 0.999), eps=1e-8, clip_max_norm=0.1,
+                 ema_flat=None):
+        self.flat, self.ema_flat = flat, ema_flat
+        self.betas, self.eps, self.clip = betas, eps, clip_max_norm
+        self.weight_decays = [float(weight_decays[g]) for g in flat.group_names]
+        self.lrs = [float(lrs[g]) for g in flat.group_names]
+        self.exp_avg = torch.zeros_like(flat.params)
+        self.exp_avg_sq = torch.zeros_like(flat.params)
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=flat.device)
+        self.hyper = torch.zeros(_HYPER_LEN, dtype=torch.float32, device=flat.device)
+        self._hyper_host = torch.zeros(_HYPER_LEN, dtype=torch.float32).pin_memory() if flat.device.type == "cuda" else torch.zeros(_HYPER_LEN)
+        self._group_begin = (_lib.ctypes.c_longlong * len(flat.group_begin))(*flat.group_begin)
+        self.t = 0
+        self.ema_decay = -1.0
+
+    def set_schedule(self, lrs=None, ema_decay=None):
+        if lrs is not None:
+            self.lrs = [float(lrs[g]) for g in self.flat.group_names]
+        if ema_decay is not None:
+            self.ema_decay = float(ema_decay)
+
+    def _upload_scalars(self):
+        """Advance the step counter and push this step's scalars (one pinned async copy)."""
+        self.t += 1
+        h = self._hyper_host
+        h[0] = self.clip if self.clip else -1.0
+        h[1], h[2], h[3] = self.betas[0], self.betas[1], self.eps
+        h[4], h[5] = 1.0 - self.betas[0] ** self.t, 1.0 - self.betas[1] ** self.t
+        h[6] = self.ema_decay if self.ema_flat is not None else -1.0
+        for g, (lr, wd) in enumerate(zip(self.lrs, self.weight_decays)):
+            h[_GROUP_OFF + 2 * g], h[_GROUP_OFF + 2 * g + 1] = lr, wd
+        self.hyper.copy_(h, non_blocking=True)
+
+    def launch(self):
+        """The device work of one step (graph-capturable: no host values are baked in)."""
+        lib = _lib.load()
+        f = self.flat
+        st = _lib.stream_ptr()
+        self.sumsq.zero_()
+        with _lib.timed("grad_sumsq", f.numel * 4):
+            _lib.check(lib.dfine_grad_sumsq(_lib.ptr(f.grads), f.numel, _lib.ptr(self.sumsq), st), "dfine_grad_sumsq")
+        n_streams = 8 + (2 if self.ema_flat is not None else 0)  # p,g,m,v read and written (+ ema read and written)
+        with _lib.timed("adamw_ema_step", f.numel * 4 * n_streams):
+            rc = lib.dfine_adamw_ema_step(_lib.ptr(f.params), _lib.ptr(f.grads), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                          _lib.ptr(self.ema_flat), None, _lib.ptr(self.hyper), _lib.ptr(self.sumsq),
+                                          self._group_begin, len(f.group_begin), f.numel, st)
+        _lib.check(rc, "dfine_adamw_ema_step")
+
+    def step(self):
+        self._upload_scalars()
+        self.launch()
+
+    def grad_norm(self):
+        """Total gradient norm of the LAST step (device tensor)."""
+        return self.sumsq.sqrt().float()
+
+
+def one_cycle_lr(step, total_steps, max_lr, pct_start=0.1, div_factor=25.0, final_div_factor=1e4):
+    """torch.optim.lr_scheduler.OneCycleLR (cos annealing, two phases) as a pure function of the
+    step index -- the reference's schedule (src/dl/train.py:193-208) without a stateful scheduler,
+    so the learning rate can be fed to the fused optimizer as data."""
+    initial, minimum = max_lr / div_factor, max_lr / div_factor / final_div_factor
+    up_end = float(pct_start * total_steps) - 1
+    last = total_steps - 1
+
+    def cos(a, b, pct):
+        return b + (a - b) / 2.0 * (math.cos(math.pi * pct) + 1)
+
+    step = min(step, last)
+    if step <= up_end:
+        return cos(initial, max_lr, step / up_end if up_end > 0 else 1.0)
+    return cos(max_lr, minimum, (step - up_end) / (last - up_end))

@@ -2,88 +2,134 @@
 (src/dl/train.py:488-562: autocast forward, criterion outside autocast, backward, clip 0.1,
 AdamW over four groups, OneCycle LR, EMA) without its per-iteration host work (``loss.item()``,
 an ``nvidia-smi`` subprocess, per-tensor target copies).
+
+On the GPU the whole step -- forward, criterion with device-side matching, backward, fused
+clip+AdamW+EMA -- issues no host synchronisation and reads every per-step scalar from device
+memory, so after a few eager steps it is captured once into a hipGraph and replayed: the step is
+otherwise bound by the ~9 000 kernel launches of the eager path, not by the GPU.
 """
 import math
 from copy import deepcopy
 
 import torch
 
-from .dfine import build_loss, build_model, build_optimizer
+from .dfine import build_loss, build_model
+from .layers import ConvNorm
+from .optim import FlatState, FusedAdamWEMA, one_cycle_lr
 from .targets import TargetBatch
 
 
 class ModelEMA:
     """Exponential moving average of the weights (train.py:51-72): decay
-    momentum*(1-exp(-iters/2000)) over every floating-point state_dict entry."""
+    momentum*(1-exp(-iters/2000)) over every floating-point state_dict entry. The parameters are
+    averaged inside the fused optimizer kernel; this class owns the copy and averages the buffers
+    (BatchNorm statistics etc.)."""
 
     def __init__(self, model, momentum=0.9998):
         self.model = deepcopy(model).eval()
         for p in self.model.parameters():
             p.requires_grad_(False)
         self.momentum = momentum
-        self._pairs = None
+        src = dict(model.named_buffers())
+        pairs = [(b, src[k]) for k, b in self.model.named_buffers() if b.dtype.is_floating_point]
+        self._ema_bufs, self._cur_bufs = [a for a, _ in pairs], [b for _, b in pairs]
 
     def decay(self, iters):
         return self.momentum * (1 - math.exp(-iters / 2000))
 
-    def update(self, iters, model):
-        if self._pairs is None:
-            src = model.state_dict()
-            pairs = [(t, src[k]) for k, t in self.model.state_dict().items() if t.dtype.is_floating_point]
-            self._pairs = ([a for a, _ in pairs], [b for _, b in pairs])
-        d = self.decay(iters)
-        ema, cur = self._pairs
+    def update_buffers(self, decay_tensor):
+        """ema = decay*ema + (1-decay)*current for the float buffers; ``decay_tensor`` is a 0-dim device
+        tensor so the same launches serve every step (mul/add form: anchors hold +inf, a lerp would NaN)."""
+        if not self._ema_bufs:
+            return
         with torch.no_grad():
-            torch._foreach_mul_(ema, d)
-            torch._foreach_add_(ema, cur, alpha=1.0 - d)
+            w = 1.0 - decay_tensor
+            torch._foreach_mul_(self._ema_bufs, decay_tensor)
+            torch._foreach_addcmul_(self._ema_bufs, self._cur_bufs, [w] * len(self._cur_bufs))
 
 
 class TrainStep:
-    """model + criterion + optimizer + scheduler + EMA; ``step(images, targets)`` runs one
-    iteration and returns the (device-resident) total loss. No host synchronisation inside."""
+    """model + criterion + fused optimizer + OneCycle schedule + EMA; ``step(images, targets)`` runs
+    one iteration and returns the (device-resident) total loss."""
 
     def __init__(self, model_name="m", num_classes=80, enable_mask_head=False, img_size=(640, 640),
                  device="cuda", base_lr=1.5e-4, backbone_lr=2e-5, betas=(0.9, 0.999), weight_decay=1.25e-4,
                  clip_max_norm=0.1, use_ema=True, ema_momentum=0.9998, amp=True, total_steps=10000,
-                 pct_start=0.1, grad_reducer=None):
+                 pct_start=0.1, grad_reducer=None, use_graph=True, graph_warmup=3):
         self.device = torch.device(device)
         self.num_classes = num_classes
         self.model = build_model(model_name, num_classes, enable_mask_head, self.device, img_size=list(img_size))
         self.criterion = build_loss(model_name, num_classes, 0.0, enable_mask_head)
-        self.optimizer = build_optimizer(self.model, lr=base_lr, backbone_lr=backbone_lr, betas=betas,
-                                         weight_decay=weight_decay, base_lr=base_lr)
-        max_lr = base_lr * 2
-        if model_name in ("l", "x"):
-            max_lr = [backbone_lr * 2, backbone_lr * 2, base_lr * 2, base_lr * 2]
-        self.scheduler = torch.optim.lr_scheduler.OneCycleLR(
-            self.optimizer, max_lr=max_lr, total_steps=total_steps, pct_start=pct_start, cycle_momentum=False)
         self.ema = ModelEMA(self.model, ema_momentum) if use_ema else None
-        self.clip_max_norm = clip_max_norm
+        self.flat = FlatState(self.model)
+        ema_flat = self.flat.mirror(self.ema.model) if self.ema is not None else None
+        # groups and max learning rates as in train.py:184-208 (OneCycle peaks at 2x the configured lr)
+        self.max_lrs = {"backbone": backbone_lr * 2, "backbone_norm": backbone_lr * 2,
+                        "encdec_norm_bias": base_lr * 2, "rest": base_lr * 2}
+        wds = {"backbone": weight_decay, "backbone_norm": 0.0, "encdec_norm_bias": 0.0, "rest": weight_decay}
+        self.optimizer = FusedAdamWEMA(self.flat, self.max_lrs, wds, betas=betas, clip_max_norm=clip_max_norm, ema_flat=ema_flat)
+        self.total_steps, self.pct_start = total_steps, pct_start
         self.amp = amp and self.device.type == "cuda"
         self.iters = 0
-        self.grad_reducer = grad_reducer(self.model) if grad_reducer is not None else None
+        self.grad_reducer = grad_reducer(self.flat) if grad_reducer is not None else None
+        if self.grad_reducer is not None:  # non-trainable state is not in the flat buffer: align it once
+            for t in list(self.model.buffers()) + [p for p in self.model.parameters() if not p.requires_grad]:
+                torch.distributed.broadcast(t, src=0)
+        self.use_graph = use_graph and self.device.type == "cuda" and self.grad_reducer is None
+        self.graph_warmup = graph_warmup
+        self._graphs = {}  # (batch, max_gt, has_gt) -> (graph, static images, static TargetBatch, static loss)
+        self._conv_norms = [m for m in self.model.modules() if isinstance(m, ConvNorm)]
         self.model.train()
 
-    def step(self, images, targets):
-        model = self.model
-        tb = TargetBatch.from_list(targets, self.num_classes, self.device)
-        images = images.to(self.device, non_blocking=True)
+    # ------------------------------------------------------------------ one step, device side
+    def _body(self, images, tb):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
-            out = model(images, targets=tb)
+            out = self.model(images, targets=tb)
         losses = self.criterion(out)  # fp32, outside autocast like train.py:548-549
         loss = sum(losses.values())
         loss.backward()
         if self.grad_reducer is not None:
-            self.grad_reducer.finish()  # wait for the bucketed all-reduces issued during backward
-        if self.clip_max_norm:
-            torch.nn.utils.clip_grad_norm_(model.parameters(), self.clip_max_norm, foreach=True)
-        self.optimizer.step()
-        self.scheduler.step()
-        if self.grad_reducer is not None:
-            self.grad_reducer.zero_grad()  # grads are views into the reducer's flat buckets
-        else:
-            self.optimizer.zero_grad(set_to_none=True)
-        self.iters += 1
+            self.grad_reducer.finish()
+        self.optimizer.launch()  # clip + AdamW + EMA(params) + zero grads
         if self.ema is not None:
-            self.ema.update(self.iters, model)
+            self.ema.update_buffers(self.optimizer.hyper[6])
         return loss.detach()
+
+    def _schedule(self):
+        lrs = {g: one_cycle_lr(self.iters, self.total_steps, m, self.pct_start) for g, m in self.max_lrs.items()}
+        self.iters += 1
+        decay = self.ema.decay(self.iters) if self.ema is not None else None
+        self.optimizer.set_schedule(lrs, decay)
+        self.optimizer._upload_scalars()
+
+    def step(self, images, targets):
+        tb = TargetBatch.from_list(targets, self.num_classes, self.device)
+        images = images.to(self.device, non_blocking=True)
+        self._schedule()
+        if not self.use_graph or tb.masks is not None or self.iters <= self.graph_warmup:
+            return self._body(images, tb)
+        key = (tuple(images.shape), tb.max_gt, max(tb.num_gts), tb.total > 0)
+        entry = self._graphs.get(key)
+        if entry is None:
+            entry = self._graphs[key] = self._capture(images, tb)
+        graph, s_images, s_tb, s_loss = entry
+        s_images.copy_(images, non_blocking=True)
+        s_tb.labels.copy_(tb.labels, non_blocking=True)
+        s_tb.boxes.copy_(tb.boxes, non_blocking=True)
+        s_tb.valid.copy_(tb.valid, non_blocking=True)
+        s_tb.counts.copy_(tb.counts, non_blocking=True)
+        graph.replay()
+        for m in self._conv_norms:  # host-side batch counters the replay does not run
+            m._pending_batches += 1
+        return s_loss
+
+    def _capture(self, images, tb):
+        """Capture the step for this (batch shape, padded GT width, max GT count). The per-image GT
+        counts inside may vary between replays; the maximum (it fixes the number of denoising
+        queries) may not -- a new maximum gets its own graph."""
+        s_images = images.clone()
+        s_tb = TargetBatch(tb.labels.clone(), tb.boxes.clone(), tb.valid.clone(), list(tb.num_gts), tb.counts.clone(), None)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            s_loss = self._body(s_images, s_tb)
+        return graph, s_images, s_tb, s_loss

@@ -154,6 +154,24 @@ int dfine_bn_act_bwd(const void* x, const void* addend, const void* dy, int dtyp
                      float* dgamma, float* dbeta, float* dlab, int n_pix, int C, int act, int training,
                      float eps, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Optimizer tail over FLAT fp32 buffers of n elements (all trainable parameters, grouped).
+ * Replaces clip_grad_norm_ + AdamW.step + zero_grad + ModelEMA.update of the reference's
+ * optimizer_step (src/dl/train.py:488-511, 61-72; groups from src/d_fine/dfine.py:87-124).
+ *
+ * dfine_grad_sumsq:      out[0] += sum(grad^2)   (out f64, zeroed by the caller; grad 16-byte aligned)
+ * dfine_adamw_ema_step:  g = grad * min(1, max_norm / (sqrt(sumsq) + 1e-6));  AdamW (decoupled weight
+ *     decay, PyTorch semantics);  ema = decay*ema + (1-decay)*param;  bf16_shadow = bf16(param);
+ *     grad = 0.   ema / bf16_shadow may be NULL.
+ *   hyper f32 (device): [0] max_norm (<=0 off) [1] beta1 [2] beta2 [3] eps [4] 1-beta1^t [5] 1-beta2^t
+ *                       [6] ema decay (<0 off)  [8+2g] lr of group g  [9+2g] weight decay of group g
+ *   group_begin host int64 [n_groups]: first flat index of each group (group_begin[0] == 0), <= 8 groups
+ * ------------------------------------------------------------------------------------- */
+int dfine_grad_sumsq(const float* grad, long long n, double* out, void* stream);
+int dfine_adamw_ema_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
+                         void* bf16_shadow, const float* hyper, const double* grad_sumsq,
+                         const long long* group_begin, int n_groups, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

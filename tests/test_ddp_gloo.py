@@ -11,6 +11,7 @@ import torch.nn as nn
 
 import dfine_seg_amd  # noqa: F401
 from dfine_seg_amd.ddp import BucketedGradReducer, assign_buckets
+from dfine_seg_amd.optim import FlatState
 
 
 class Toy(nn.Module):
@@ -82,8 +83,8 @@ def test_bucketed_reducer_world2_gloo():
 
 def test_bucket_assignment_covers_every_trainable_parameter_once():
     model = Toy()
-    buckets = assign_buckets(model.named_parameters(), num_buckets=3, min_bucket_bytes=64)
-    names = [n for b in buckets for n, _ in b]
+    buckets = assign_buckets(FlatState(model).entries, num_buckets=3, min_bucket_bytes=64)
+    names = [e[0] for b in buckets for e in b]
     trainable = [n for n, p in model.named_parameters() if p.requires_grad]
     assert sorted(names) == sorted(trainable) and len(names) == len(set(names))
     assert names[0].startswith("c.")  # last registered first: backward produces it first

@@ -85,8 +85,19 @@ def test_eval_forward_matches_reference(hip_lib, fname):
     model.eval()
     with torch.no_grad():
         ev = model(x)
-    assert _rel(ev["pred_logits"], g["eval.pred_logits"]) < 5e-4
-    assert _rel(ev["pred_boxes"], g["eval.pred_boxes"]) < 5e-4
+    # Eval runs its own top-k: queries whose scores tie to ~1e-6 may swap places between two fp32
+    # pipelines, so rows are compared in a canonical order (sorted by box centre) per image.
+    def canon(boxes, logits):
+        boxes, logits = torch.as_tensor(boxes).float().cpu(), torch.as_tensor(logits).float().cpu()
+        key = (boxes[..., 0] * 1e3).round() * 1e4 + (boxes[..., 1] * 1e3).round() + boxes[..., 2]
+        order = key.argsort(dim=1)
+        pick = lambda t: t.gather(1, order.unsqueeze(-1).expand_as(t))
+        return pick(boxes), pick(logits)
+
+    got_b, got_l = canon(ev["pred_boxes"].detach(), ev["pred_logits"].detach())
+    ref_b, ref_l = canon(g["eval.pred_boxes"], g["eval.pred_logits"])
+    assert _rel(got_l, ref_l) < 5e-4
+    assert _rel(got_b, ref_b) < 5e-4
     if seg:
         assert _rel(_sample(ev["pred_masks"], 4096)[0], g["eval.pred_masks.sample"]) < 1e-3
 
