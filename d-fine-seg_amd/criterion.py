@@ -21,6 +21,15 @@ from .decoder import weighting_function
 from .targets import TargetBatch
 
 _DUMMY_BOX = (0.5, 0.5, 1.0, 1.0)  # stands in for "no target" so IoU/GIoU stay finite before masking
+_dummy_cache = {}
+
+
+def _dummy_box(device):
+    """Device constant, created once (never inside a graph capture: it is a host->device copy)."""
+    key = str(device)
+    if key not in _dummy_cache:
+        _dummy_cache[key] = torch.tensor(_DUMMY_BOX, dtype=torch.float32, device=device)
+    return _dummy_cache[key]
 
 
 def _xyxy(b):
@@ -48,7 +57,7 @@ class _Matched:
         self.mask = assign >= 0  # [B, Q]
         idx = assign.clamp(min=0).long()
         box = tb.boxes.gather(1, idx.unsqueeze(-1).expand(-1, -1, 4))
-        self.boxes = torch.where(self.mask.unsqueeze(-1), box, box.new_tensor(_DUMMY_BOX))
+        self.boxes = torch.where(self.mask.unsqueeze(-1), box, _dummy_box(box.device))
         self.labels = torch.where(self.mask, tb.labels.gather(1, idx), num_classes)
 
 
@@ -232,7 +241,7 @@ class DFINECriterion(nn.Module):
         if "dn_outputs" in outputs:
             meta = outputs["dn_meta"]
             groups = meta["dn_num_group"]
-            dn_nb = num_boxes * groups if groups > 0 else num_boxes.new_tensor(1.0)
+            dn_nb = num_boxes * groups if groups > 0 else torch.ones_like(num_boxes)
             dn_nb = torch.where(dn_nb > 0, dn_nb, torch.ones_like(dn_nb))
             assign = meta["dn_assign"]
             if assign is None:

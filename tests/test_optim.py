@@ -92,11 +92,11 @@ def test_fused_adamw_ema_matches_torch(hip_lib):
                 if s.requires_grad:
                     e.mul_(decay).add_((1 - decay) * s)
         for n, p in model.named_parameters():
-            torch.testing.assert_close(p, ref_params[n], rtol=2e-5, atol=1e-7, msg=lambda m: f"{n} step {step}: {m}")
+            torch.testing.assert_close(p, ref_params[n], rtol=2e-5, atol=1e-6, msg=lambda m: f"{n} step {step}: {m}")
             if p.requires_grad:
                 assert float(p.grad.abs().max()) == 0.0  # zero_grad is part of the fused step
         for (n, e), (_, r) in zip(ema_model.named_parameters(), ref_ema.named_parameters()):
-            torch.testing.assert_close(e, r, rtol=2e-5, atol=1e-7)
+            torch.testing.assert_close(e, r, rtol=2e-5, atol=1e-6)
 
 
 @pytest.mark.gpu
