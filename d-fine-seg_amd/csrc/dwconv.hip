@@ -107,9 +107,6 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const T* __restric
 }
 
 // Backward w.r.t. the weights: dw[c][tap] = sum over (b,oy,ox) of dy[b,oy,ox,c] * x[b,iy,ix,c].
-// One thread = 4 channels x a strided set of output pixels, K*K*4 fp32 partial sums in registers;
-// partials of the block's pixel rows are summed through LDS, then one float atomic per (c, tap)
-// per block into dw (zeroed by the caller).
 template <typename T>
 struct Quad;  // 4 channels as one 8-byte (bf16) or 16-byte (f32) load
 template <>
@@ -130,57 +127,63 @@ struct Quad<float> {
   }
 };
 
+// One thread = 4 channels x one kernel row ky x a strided set of output rows (b, oy). Along a row it
+// slides a K-wide register window over x, so each output pixel costs one dy load and S new x loads
+// for K*4 FMAs; its K*4 partial sums go to dw with float atomics (zeroed by the caller).
+// blockDim = (channel quads, K kernel rows, rows per block).
 template <typename T, int K, int S>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x,
                                                                 const T* __restrict__ dy,
                                                                 float* __restrict__ dw, DwGeom g,
-                                                                int n_pix, int pix_per_thread) {
+                                                                int n_rows, int rows_per_thread) {
   constexpr int PAD = (K - 1) / 2;
-  constexpr int KK = K * K;
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [blockDim.y][blockDim.x][KK*4]
   const int c0 = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
-  float acc[KK][4];
+  const int ky = threadIdx.y;
+  float acc[K][4];
 #pragma unroll
-  for (int t = 0; t < KK; ++t)
+  for (int t = 0; t < K; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[t][i] = 0.f;
-  const int first = blockIdx.x * blockDim.y * pix_per_thread + threadIdx.y;
-  for (int n = 0; n < pix_per_thread; ++n) {
-    const int pix = first + n * blockDim.y;
-    if (pix >= n_pix) break;
-    const int ox = pix % g.OW, oy = (pix / g.OW) % g.OH, b = pix / (g.OW * g.OH);
-    float d[4];
-    Quad<T>::load(dy + (size_t)pix * g.C + c0, d);
-    const T* xb = x + (size_t)b * g.H * g.W * g.C + c0;
+  const int first = blockIdx.x * blockDim.z * rows_per_thread + threadIdx.z;
+  for (int n = 0; n < rows_per_thread; ++n) {
+    const int row = first + n * blockDim.z;  // (b, oy)
+    if (row >= n_rows) break;
+    const int oy = row % g.OH, b = row / g.OH;
+    const int iy = oy * S + ky - PAD;
+    if (iy < 0 || iy >= g.H) continue;
+    const T* xr = x + ((size_t)(b * g.H + iy) * g.W) * g.C + c0;
+    const T* dr = dy + ((size_t)row * g.OW) * g.C + c0;
+    float w[K][4];
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-      const int iy = oy * S + ky - PAD;
-      if (iy < 0 || iy >= g.H) continue;
+    for (int j = 0; j < K; ++j) {  // window for ox = 0: ix = j - PAD
+      const int ix = j - PAD;
+      if (ix >= 0 && ix < g.W) Quad<T>::load(xr + (size_t)ix * g.C, w[j]);
+      else w[j][0] = w[j][1] = w[j][2] = w[j][3] = 0.f;
+    }
+    for (int ox = 0; ox < g.OW; ++ox) {
+      float d[4];
+      Quad<T>::load(dr + (size_t)ox * g.C, d);
 #pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
-        const int ix = ox * S + kx - PAD;
-        if (ix < 0 || ix >= g.W) continue;
-        float v[4];
-        Quad<T>::load(xb + ((size_t)iy * g.W + ix) * g.C, v);
+      for (int j = 0; j < K; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[ky * K + kx][i] += d[i] * v[i];
+        for (int i = 0; i < 4; ++i) acc[j][i] += d[i] * w[j][i];
+      // slide by S: keep the K-S newest taps, fetch S new columns for ox+1
+#pragma unroll
+      for (int j = 0; j + S < K; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[j][i] = w[j + S][i];
+#pragma unroll
+      for (int j = K - S; j < K; ++j) {
+        const int ix = (ox + 1) * S + j - PAD;
+        if (ix >= 0 && ix < g.W) Quad<T>::load(xr + (size_t)ix * g.C, w[j]);
+        else w[j][0] = w[j][1] = w[j][2] = w[j][3] = 0.f;
       }
     }
   }
-  // block reduction over threadIdx.y
-  float* mine = red + ((size_t)threadIdx.y * blockDim.x + threadIdx.x) * (KK * 4);
 #pragma unroll
-  for (int t = 0; t < KK; ++t)
+  for (int kx = 0; kx < K; ++kx)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) mine[t * 4 + i] = acc[t][i];
-  __syncthreads();
-  const int per_col = KK * 4;
-  for (int e = threadIdx.y; e < per_col; e += blockDim.y) {
-    float s = 0.f;
-    for (int r = 0; r < (int)blockDim.y; ++r) s += red[((size_t)r * blockDim.x + threadIdx.x) * per_col + e];
-    const int t = e / 4, i = e % 4;
-    atomicAdd(dw + (size_t)(c0 + i) * KK + t, s);
-  }
+    for (int i = 0; i < 4; ++i) atomicAdd(dw + (size_t)(c0 + i) * (K * K) + ky * K + kx, acc[kx][i]);
 }
 
 static int largest_divisor_leq(int n, int cap) {
@@ -211,16 +214,18 @@ template <typename T, int K, int S>
 static int run_bwd_weight(const void* x, const void* dy, float* dw, const DwGeom& g, hipStream_t st) {
   if (g.C % 4 != 0) return DFINE_E_UNSUPPORTED;
   const int cgb = largest_divisor_leq(g.C / 4, 32);
-  const int pb = (K == 5 ? 128 : 256) / cgb;  // K*K*4 floats of LDS per thread: keep the block under 64 KiB
-  const long long n_pix = (long long)g.B * g.OH * g.OW;
-  // enough blocks to fill the chip (~2k) but >= 16 pixels per thread so atomics stay few
-  int ppt = (int)((n_pix + (long long)pb * 2048 - 1) / ((long long)pb * 2048));
-  if (ppt < 16) ppt = 16;
-  dim3 block(cgb, pb), grid((unsigned)((n_pix + (long long)pb * ppt - 1) / ((long long)pb * ppt)), g.C / (cgb * 4));
-  const size_t lds = (size_t)pb * cgb * K * K * 4 * sizeof(float);
-  if (lds > 64 * 1024) return DFINE_E_UNSUPPORTED;
-  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, S>), grid, block, lds, st, (const T*)x, (const T*)dy, dw, g,
-                     (int)n_pix, ppt);
+  int rb = 256 / (cgb * K);  // rows per block
+  if (rb < 1) rb = 1;
+  const long long n_rows = (long long)g.B * g.OH;
+  // ~4k blocks of 160-250 threads keep every CU's wave slots busy (the loop is load-latency bound);
+  // a thread's K*4 atomics per row are cheap next to its OW*(S+1) loads
+  long long want_blocks = 4096 / (g.C / (cgb * 4));
+  if (want_blocks < 1) want_blocks = 1;
+  long long rpt = (n_rows + want_blocks * rb - 1) / (want_blocks * rb);
+  if (rpt < 1) rpt = 1;
+  dim3 block(cgb, K, rb), grid((unsigned)((n_rows + (long long)rb * rpt - 1) / ((long long)rb * rpt)), g.C / (cgb * 4));
+  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, S>), grid, block, 0, st, (const T*)x, (const T*)dy, dw, g,
+                     (int)n_rows, (int)rpt);
   DFINE_LAUNCH_CHECK();
   return 0;
 }
