@@ -62,8 +62,13 @@ class _Matched:
 
 
 class DFINECriterion(nn.Module):
-    def __init__(self, spec: CriterionSpec = None, num_classes=80, losses=("vfl", "boxes", "local"), label_smoothing=0.0):
+    def __init__(self, spec: CriterionSpec = None, num_classes=80, losses=("vfl", "boxes", "local"), label_smoothing=0.0,
+                 fused=True):
+        """``fused``: on the GPU, compute vfl / boxes / local of each head (and their gradients) with the
+        single HIP kernel behind ``ops.criterion_head``; the dense PyTorch formulation below is the
+        same math op by op and is what the kernel is tested against."""
         super().__init__()
+        self.fused = fused
         self.spec = spec or CriterionSpec()
         self.num_classes = num_classes
         self.losses = tuple(losses)
@@ -182,7 +187,7 @@ class DFINECriterion(nn.Module):
         if tb is None:
             tb = TargetBatch.from_list(targets, C, dev)
         aux, enc = outputs["aux_outputs"], outputs["enc_aux_outputs"]
-        main = {k: outputs[k] for k in ("pred_logits", "pred_boxes", "pred_corners", "ref_points", "up", "reg_scale", "pred_masks") if k in outputs}
+        main = {k: outputs[k] for k in ("pred_logits", "pred_boxes", "pred_corners", "ref_points", "pred_masks") if k in outputs}
         heads = [main] + list(aux) + [outputs["pre_outputs"]] + list(enc)
         # ---- all matchings of the step at once (matcher.py:52-130 x (L+2))
         logits = torch.stack([h["pred_logits"].detach().float() for h in heads])
@@ -200,65 +205,138 @@ class DFINECriterion(nn.Module):
         norm = (norm / world).clamp(min=1)
         num_boxes_go, num_boxes = norm[0], norm[1]
 
-        m_go = _Matched(go, tb, C)
         fdr = outputs.get("fdr")
         if fdr is None:  # outputs not produced by this package's decoder: read the Parameters (one sync)
             fdr = {"W": weighting_function(spec.reg_max, outputs["up"], outputs["reg_scale"]).to(dev),
                    "reg_scale": float(outputs["reg_scale"].detach().abs().reshape(-1)[0])}
-        cache, losses = {"fdr": fdr}, {}
         with_masks = "masks" in self.losses
         pairs_bg = self._host_pairs(tb.num_gts, dev) if with_masks else None
+        cache, losses = {"fdr": fdr}, {}
 
-        def add(out, suffix, own, own_idx, use_go=("boxes", "local"), is_dn=False, nb_own=num_boxes, nb_go=num_boxes_go):
-            res = {}
-            for name in self.losses:
-                m, nb = (m_go, nb_go) if (name in use_go) else (own, nb_own)
-                if name == "vfl":
-                    res.update(self.loss_vfl(out, m, nb))
-                elif name == "boxes":
-                    res.update(self.loss_boxes(out, m, nb))
-                elif name == "local":
-                    res.update(self.loss_local(out, m, nb, cache, is_dn))
-                elif name == "masks":
-                    res.update(self.loss_masks(out, own_idx, tb, cache))
-            losses.update({k + suffix: v * self.weight_dict[k] for k, v in res.items() if k in self.weight_dict})
-
-        def own_of(h):
-            pairs = None
-            if with_masks:
-                b, g = pairs_bg
-                pairs = (b, query_of_gt[h].long()[b, g], g)
-            return _Matched(gt_of_query[h], tb, C), pairs
-
-        shared = {"up": outputs["up"], "reg_scale": outputs["reg_scale"]}
-        add(main, "", *own_of(0))
-        for i, out in enumerate(aux):
-            add({**out, **shared}, f"_aux_{i}", *own_of(1 + i))
-        add(outputs["pre_outputs"], "_pre", *own_of(1 + len(aux)))
-        for i, out in enumerate(enc):
-            add(out, f"_enc_{i}", *own_of(2 + len(aux) + i), use_go=("boxes",))
-
-        if "dn_outputs" in outputs:
+        # ---- denoising heads: deterministic matching (get_cdn_matched_indices, :610-632), dense
+        has_dn = "dn_outputs" in outputs
+        if has_dn:
             meta = outputs["dn_meta"]
             groups = meta["dn_num_group"]
             dn_nb = num_boxes * groups if groups > 0 else torch.ones_like(num_boxes)
-            dn_nb = torch.where(dn_nb > 0, dn_nb, torch.ones_like(dn_nb))
-            assign = meta["dn_assign"]
-            if assign is None:
-                assign = torch.full(outputs["dn_pre_outputs"]["pred_logits"].shape[:2], -1, dtype=torch.int32, device=dev)
-            m_dn = _Matched(assign, tb, C)
+            dn_assign = meta["dn_assign"]
+            if dn_assign is None:
+                dn_assign = torch.full(outputs["dn_pre_outputs"]["pred_logits"].shape[:2], -1, dtype=torch.int64, device=dev)
             dn_pairs = None
             if with_masks:
                 G = max(tb.num_gts) if tb.total else 1
                 b, g = pairs_bg
                 reps = torch.arange(max(groups, 0), device=dev)
                 dn_pairs = (b.repeat(max(groups, 0)), (reps[:, None] * 2 * G + g[None, :]).flatten(), g.repeat(max(groups, 0)))
-            dn_kw = dict(use_go=(), is_dn=True, nb_own=dn_nb)
-            for i, out in enumerate(outputs["dn_outputs"]):
-                add({**out, **shared}, f"_dn_{i}", m_dn, dn_pairs, **dn_kw)
-            if "dn_pred_masks" in outputs and with_masks:
-                res = self.loss_masks({"pred_masks": outputs["dn_pred_masks"]}, dn_pairs, tb, cache)
-                losses.update({k + "_dn_final": v * self.weight_dict[k] for k, v in res.items()})
-            add(outputs["dn_pre_outputs"], "_dn_pre", m_dn, dn_pairs, **dn_kw)
 
+        def own_pairs(h):
+            if not with_masks:
+                return None
+            b, g = pairs_bg
+            return b, query_of_gt[h].long()[b, g], g
+
+        def mask_terms(out, pairs, suffix):
+            if with_masks:
+                res = self.loss_masks(out, pairs, tb, cache)
+                losses.update({k + suffix: v * self.weight_dict[k] for k, v in res.items() if k in self.weight_dict})
+
+        if self.fused and dev.type == "cuda":
+            head = self._fused_heads(tb, go, gt_of_query, num_boxes, num_boxes_go, fdr, losses)
+        else:
+            head = self._dense_heads(tb, go, gt_of_query, num_boxes, num_boxes_go, cache, losses)
+
+        # order of the reference's loss dict: main, aux_i, pre, enc_i, dn_i, dn_final (masks), dn_pre
+        head(main, "", 0, local=True)
+        mask_terms(main, own_pairs(0), "")
+        for i, out in enumerate(aux):
+            head(out, f"_aux_{i}", 1 + i, local=True)
+            mask_terms(out, own_pairs(1 + i), f"_aux_{i}")
+        head(outputs["pre_outputs"], "_pre", 1 + len(aux), local=True)
+        mask_terms(outputs["pre_outputs"], own_pairs(1 + len(aux)), "_pre")
+        for i, out in enumerate(enc):
+            head(out, f"_enc_{i}", 2 + len(aux) + i, local=False)
+            mask_terms(out, own_pairs(2 + len(aux) + i), f"_enc_{i}")
+        if has_dn:
+            for i, out in enumerate(outputs["dn_outputs"]):
+                head(out, f"_dn_{i}", None, local=True, dn=(dn_assign, dn_nb))
+                mask_terms(out, dn_pairs, f"_dn_{i}")
+            if "dn_pred_masks" in outputs and with_masks:
+                mask_terms({"pred_masks": outputs["dn_pred_masks"]}, dn_pairs, "_dn_final")
+            head(outputs["dn_pre_outputs"], "_dn_pre", None, local=True, dn=(dn_assign, dn_nb))
+            mask_terms(outputs["dn_pre_outputs"], dn_pairs, "_dn_pre")
         return {k: torch.nan_to_num(v, nan=0.0) for k, v in losses.items()}
+
+    # ------------------------------------------------------------------ per-head loss terms: HIP
+    def _fused_heads(self, tb, go, gt_of_query, num_boxes, num_boxes_go, fdr, losses):
+        """vfl + boxes + local of a head, and their gradients, in ONE kernel launch
+        (ops.criterion_head); the normalisers and DDF coefficients are device scalars."""
+        spec = self.spec
+        dev = go.device
+        key = ("loss_weights", str(dev))
+        if key not in self.__dict__:  # built once (a host->device copy: never inside a graph capture)
+            order = ("loss_vfl", "loss_bbox", "loss_giou", "loss_fgl", "loss_ddf")
+            self.__dict__[key] = torch.tensor([float(self.weight_dict[k]) for k in order], dtype=torch.float32, device=dev)
+        weights = self.__dict__[key]
+        B, Q = go.shape
+        n_pos = 4.0 * (go >= 0).sum().float()  # matched / unmatched edges of the GO matching
+        n_neg = 4.0 * B * Q - n_pos
+        w_pos, w_neg = (n_pos * (8.0 / B)).sqrt(), (n_neg * (8.0 / B)).sqrt()  # num_pos / num_neg (:223-230)
+        share_pos, share_neg = w_pos / (w_pos + w_neg), w_neg / (w_pos + w_neg)
+        scal_main = torch.cat([torch.stack([1.0 / num_boxes, 1.0 / num_boxes_go, share_pos / n_pos.clamp(min=1),
+                                            share_neg / n_neg.clamp(min=1)]), weights])
+        state = {}
+
+        def head(out, suffix, h, local, dn=None):
+            if dn is None:
+                own, both, scal = gt_of_query[h], go, scal_main
+            else:
+                dn_assign, dn_nb = dn
+                if dn_assign.shape[1] == 0:  # no denoising queries in this batch: every term is zero
+                    zero = num_boxes * 0
+                    names = ["loss_vfl", "loss_bbox", "loss_giou"] + (["loss_fgl", "loss_ddf"] if "pred_corners" in out else [])
+                    losses.update({n + suffix: zero for n in names})
+                    return
+                if "scal_dn" not in state:
+                    p = 4.0 * (dn_assign >= 0).sum().float()
+                    n = 4.0 * dn_assign.shape[0] * dn_assign.shape[1] - p
+                    state["scal_dn"] = torch.cat([torch.stack([1.0 / dn_nb, 1.0 / dn_nb, share_pos / p.clamp(min=1),
+                                                               share_neg / n.clamp(min=1)]), weights])
+                    state["dn_assign"] = dn_assign.to(torch.int32).contiguous()
+                own = both = state["dn_assign"]
+                scal = state["scal_dn"]
+            corners = out.get("pred_corners") if local else None
+            distil = corners is not None and out.get("teacher_corners") is not None and not out.get("self_distilled")
+            terms = ops.criterion_head(
+                out["pred_logits"], out["pred_boxes"], corners, out.get("ref_points"),
+                out["teacher_corners"] if distil else None, out["teacher_logits"] if distil else None,
+                own, both, tb.labels, tb.boxes, fdr["W"], scal, spec.alpha, spec.gamma, fdr["reg_scale"], spec.ddf_temperature)
+            names = ["loss_vfl", "loss_bbox", "loss_giou"]
+            if corners is not None:
+                names.append("loss_fgl")
+                if out.get("teacher_corners") is not None:
+                    names.append("loss_ddf")  # exactly 0 for the self-distilled layer, like the reference
+            losses.update({n + suffix: t for n, t in zip(names, terms)})
+
+        return head
+
+    # ------------------------------------------------------------------ per-head loss terms: dense PyTorch
+    def _dense_heads(self, tb, go, gt_of_query, num_boxes, num_boxes_go, cache, losses):
+        C = self.num_classes
+        m_go = _Matched(go, tb, C)
+        state = {}
+
+        def head(out, suffix, h, local, dn=None):
+            if dn is None:
+                own, nb_own, other, nb_other = _Matched(gt_of_query[h], tb, C), num_boxes, m_go, num_boxes_go
+            else:
+                if "m_dn" not in state:
+                    state["m_dn"] = _Matched(dn[0], tb, C)
+                own = other = state["m_dn"]
+                nb_own = nb_other = dn[1]
+            res = dict(self.loss_vfl(out, own, nb_own))
+            res.update(self.loss_boxes(out, other, nb_other))
+            if local:
+                res.update(self.loss_local(out, other, nb_other, cache, dn is not None))
+            losses.update({k + suffix: v * self.weight_dict[k] for k, v in res.items() if k in self.weight_dict})
+
+        return head

@@ -293,3 +293,67 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, lab_scal
 def batch_norm_act_supported(x, channels):
     """Any channel count (narrow vectors for odd counts, e.g. D-FINE-n's 21-channel CSP branch)."""
     return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
+
+
+class _CriterionHead(torch.autograd.Function):
+    """Weighted loss terms of one head + their gradients; see include/dfine_hip.h (dfine_criterion_head)."""
+
+    @staticmethod
+    def forward(ctx, logits, boxes, corners, ref_points, teacher_corners, teacher_logits, own, go, tgt_labels,
+                tgt_boxes, Wn, scalars, alpha, gamma, reg_scale, temperature):
+        _lib.require_gpu(logits, boxes, own, go)
+        lib = _lib.load()
+        B, Q, C = logits.shape
+        G = tgt_labels.shape[1]
+        dev = logits.device
+        if logits.dtype not in (torch.float32, torch.bfloat16):
+            logits = logits.float()
+        logits, boxes = logits.contiguous(), boxes.float().contiguous()
+        has_local = corners is not None
+        has_ddf = has_local and teacher_corners is not None
+        n_bins = corners.shape[-1] // 4 if has_local else 0
+        if has_local:
+            corners, ref_points = corners.float().contiguous(), ref_points.float().contiguous()
+        if has_ddf:
+            teacher_corners = teacher_corners.float().contiguous()
+            teacher_logits = teacher_logits.to(logits.dtype).contiguous()
+        terms = torch.zeros(5, dtype=torch.float32, device=dev)
+        d_logits = torch.empty_like(logits)
+        d_l1 = torch.empty(B, Q, 4, dtype=torch.float32, device=dev)
+        d_giou = torch.empty_like(d_l1)
+        d_fgl = torch.empty_like(corners) if has_local else None
+        d_ddf = torch.empty_like(corners) if has_ddf else None
+        with _lib.timed("criterion_head", logits.numel() * logits.element_size() * 2 + (corners.numel() * 16 if has_local else 0)):
+            rc = lib.dfine_criterion_head(
+                _lib.ptr(logits), _lib.dtype_code(logits), _lib.ptr(boxes), _lib.ptr(corners), _lib.ptr(ref_points),
+                _lib.ptr(teacher_corners) if has_ddf else None, _lib.ptr(teacher_logits) if has_ddf else None,
+                _lib.ptr(own), _lib.ptr(go), _lib.ptr(tgt_labels), _lib.ptr(tgt_boxes), _lib.ptr(Wn), _lib.ptr(scalars),
+                _lib.ptr(terms), _lib.ptr(d_logits), _lib.ptr(d_l1), _lib.ptr(d_giou), _lib.ptr(d_fgl), _lib.ptr(d_ddf),
+                B, Q, C, G, n_bins, alpha, gamma, reg_scale, temperature, _lib.stream_ptr())
+        _lib.check(rc, "dfine_criterion_head")
+        ctx.save_for_backward(d_logits, d_l1, d_giou, d_fgl, d_ddf)
+        ctx.mark_non_differentiable()
+        return tuple(terms.unbind(0))
+
+    @staticmethod
+    def backward(ctx, g_vfl, g_l1, g_giou, g_fgl, g_ddf):
+        d_logits, d_l1, d_giou, d_fgl, d_ddf = ctx.saved_tensors
+        grad_logits = d_logits * g_vfl.to(d_logits.dtype)
+        grad_boxes = torch.addcmul(d_l1 * g_l1, d_giou, g_giou)
+        grad_corners = None
+        if d_fgl is not None:
+            grad_corners = d_fgl * g_fgl
+            if d_ddf is not None:
+                grad_corners = torch.addcmul(grad_corners, d_ddf, g_ddf)
+        return (grad_logits, grad_boxes, grad_corners) + (None,) * 13
+
+
+def criterion_head(logits, boxes, corners, ref_points, teacher_corners, teacher_logits, own_assign, go_assign,
+                   tgt_labels, tgt_boxes, Wn, scalars, alpha=0.75, gamma=2.0, reg_scale=4.0, temperature=5.0):
+    """Weighted (loss_vfl, loss_bbox, loss_giou, loss_fgl, loss_ddf) of one prediction head as five
+    0-dim tensors, differentiable w.r.t. logits, boxes and corners. ``corners`` None: no FGL/DDF
+    (their terms are 0); ``teacher_*`` None: no DDF. ``scalars``: device float [9], see dfine_hip.h."""
+    return _CriterionHead.apply(logits, boxes, corners, ref_points, teacher_corners, teacher_logits,
+                                own_assign.contiguous(), go_assign.contiguous(), tgt_labels.contiguous(),
+                                tgt_boxes.contiguous(), Wn, scalars, float(alpha), float(gamma), float(reg_scale),
+                                float(temperature))

@@ -172,6 +172,31 @@ int dfine_adamw_ema_step(float* param, float* grad, float* exp_avg, float* exp_a
                          void* bf16_shadow, const float* hyper, const double* grad_sumsq,
                          const long long* group_begin, int n_groups, long long n, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * All box/class/distribution losses of ONE prediction head and their gradients, in one launch.
+ * Replaces DFINECriterion.loss_labels_vfl + loss_boxes + loss_local (FGL, DDF) for one head
+ * (src/d_fine/dfine_criterion.py:92-237, with arch/utils.py:267-354 bbox2distance/translate_gt and
+ * :12-51 IoU/GIoU) AND their autograd backward, on dense matchings (assign[b][q] = gt index or -1).
+ *
+ *   logits [B,Q,C] f32|bf16 (logits_dtype)   boxes [B,Q,4] f32 cxcywh
+ *   corners [B,Q,4*n_bins] f32 or NULL (no FGL/DDF)   ref_points [B,Q,4] f32
+ *   teacher_corners [B,Q,4*n_bins] f32 / teacher_logits [B,Q,C] (logits dtype), or both NULL (no DDF)
+ *   own_assign [B,Q] int32: matching used by the varifocal loss; go_assign [B,Q] int32: by boxes/FGL/DDF
+ *   tgt_labels [B,G] int64, tgt_boxes [B,G,4] f32, Wn [n_bins] f32 = W(n)
+ *   scalars f32 [9] (device): 1/num_boxes (vfl), 1/num_boxes (boxes, FGL), DDF coefficient of a matched
+ *       edge, of an unmatched edge, then the 5 loss weights (vfl, bbox, giou, fgl, ddf)
+ *   terms f32 [5]: weighted loss_vfl, loss_bbox, loss_giou, loss_fgl, loss_ddf -- ACCUMULATED (caller zeroes)
+ *   d_logits [B,Q,C] (logits dtype), d_boxes_l1 / d_boxes_giou [B,Q,4], d_corners_fgl / d_corners_ddf
+ *       [B,Q,4*n_bins] f32: gradient of the corresponding weighted term (overwritten)
+ * ------------------------------------------------------------------------------------- */
+int dfine_criterion_head(const void* logits, int logits_dtype, const float* boxes, const float* corners,
+                         const float* ref_points, const float* teacher_corners, const void* teacher_logits,
+                         const int32_t* own_assign, const int32_t* go_assign, const int64_t* tgt_labels,
+                         const float* tgt_boxes, const float* Wn, const float* scalars, float* terms,
+                         void* d_logits, float* d_boxes_l1, float* d_boxes_giou, float* d_corners_fgl,
+                         float* d_corners_ddf, int B, int Q, int C, int G, int n_bins, float alpha, float gamma,
+                         float reg_scale, float temperature, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
