@@ -25,7 +25,8 @@ SIGNATURES = {
     "dfine_go_union": [_c_void_p] * 2 + [_c_int] * 3 + [_c_void_p],
     "dfine_dwconv_fwd": [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p],
     "dfine_dwconv_bwd_data": [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p],
-    "dfine_dwconv_bwd_weight": [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p],
+    "dfine_dwconv_bwd_weight": [_c_void_p] * 4 + [ctypes.c_longlong] + [_c_int] * 7 + [_c_void_p],
+    "dfine_dwconv_bwd_weight_workspace": [_c_int] * 6,
     "dfine_bn_act_fwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 9 + [_c_int] * 4 + [ctypes.c_float] * 2 + [_c_void_p],
     "dfine_criterion_head": [_c_void_p, _c_int] + [_c_void_p] * 17 + [_c_int] * 5 + [ctypes.c_float] * 4 + [_c_void_p],
     "dfine_grad_sumsq": [_c_void_p, ctypes.c_longlong, _c_void_p, _c_void_p],
@@ -55,7 +56,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = _c_int
+        fn.restype = ctypes.c_longlong if name.endswith("_workspace") else _c_int
     got = lib.dfine_abi_version()
     if got != ABI_VERSION:
         raise DfineHipError(f"libdfine_hip.so ABI {got} != expected {ABI_VERSION}: rebuild it")

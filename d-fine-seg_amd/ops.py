@@ -196,8 +196,13 @@ class _DepthwiseConv2d(torch.autograd.Function):
             dx = dx.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             dw = torch.zeros(C, 1, k, k, dtype=torch.float32, device=xl.device)
+            n_ws = lib.dfine_dwconv_bwd_weight_workspace(B, H, W, C, k, stride)
+            if n_ws < 0:
+                raise _lib.DfineHipError(f"depthwise conv weight gradient: unsupported shape C={C} k={k} stride={stride}")
+            ws = torch.empty(n_ws, dtype=torch.float32, device=xl.device)
             with _lib.timed("dwconv_bwd_weight", (gy.numel() + xl.numel()) * gy.element_size() + w.numel() * 4):
-                rc = lib.dfine_dwconv_bwd_weight(_lib.ptr(xl), _lib.ptr(gy), _lib.ptr(dw), code, B, H, W, C, k, stride, st)
+                rc = lib.dfine_dwconv_bwd_weight(_lib.ptr(xl), _lib.ptr(gy), _lib.ptr(dw), _lib.ptr(ws), n_ws, code,
+                                                 B, H, W, C, k, stride, st)
             _lib.check(rc, "dfine_dwconv_bwd_weight")
             dw = dw.to(w_dtype)
         return dx, dw, None

@@ -86,7 +86,7 @@ class TrainStep:
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
             out = self.model(images, targets=tb)
         losses = self.criterion(out)  # fp32, outside autocast like train.py:548-549
-        loss = sum(losses.values())
+        loss = torch.stack(list(losses.values())).sum()  # one reduction instead of a chain of ~50 adds
         loss.backward()
         if self.grad_reducer is not None:
             self.grad_reducer.finish()

@@ -125,8 +125,12 @@ int dfine_dwconv_fwd(const void* x, const float* w, void* y, int dtype, int B, i
                      int k, int stride, void* stream);
 int dfine_dwconv_bwd_data(const void* dy, const float* w, void* dx, int dtype, int B, int H, int W,
                           int C, int k, int stride, void* stream);
-int dfine_dwconv_bwd_weight(const void* x, const void* dy, float* dw, int dtype, int B, int H, int W,
-                            int C, int k, int stride, void* stream);
+/* workspace: f32 scratch of at least dfine_dwconv_bwd_weight_workspace(...) floats (per-block partial
+ * sums, summed by a second kernel); the query returns -1 for unsupported shapes. */
+long long dfine_dwconv_bwd_weight_workspace(int B, int H, int W, int C, int k, int stride);
+int dfine_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* workspace,
+                            long long workspace_floats, int dtype, int B, int H, int W, int C, int k,
+                            int stride, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused BatchNorm2d (batch statistics) [+ addend] + activation [+ learnable affine], channel-last:

@@ -12,7 +12,7 @@ def declared_symbols():
     for header in glob.glob(os.path.join(ROOT, "include", "*.h")):
         text = open(header).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        names |= set(re.findall(r"\bint\s+(dfine_\w+)\s*\(", text))
+        names |= set(re.findall(r"\b(?:int|long long)\s+(dfine_\w+)\s*\(", text))
     return names
 
 
