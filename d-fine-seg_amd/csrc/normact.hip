@@ -65,6 +65,11 @@ struct ColReduce {
   }
 };
 
+// Every kernel walks its pixels four at a time with the loads of all four issued before any is used
+// (the maps are 6-100 MB: at that size a kernel is latency-bound unless each wave keeps several
+// 16-byte loads in flight), and fetches its per-channel constants once per block through LDS.
+#define DFINE_NA_UNROLL 4
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, double* __restrict__ sums, NaGeom g) {
   extern __shared__ __attribute__((aligned(16))) float red[];
@@ -73,76 +78,100 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[0][i] = acc[1][i] = 0.f;
   const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
-  for (int n = 0; n < g.pix_per_thread; ++n) {
-    const int pix = first + n * blockDim.y;
-    if (pix >= g.n_pix) break;
-    float v[VEC];
-    load_vec<T, VEC>(x + (size_t)pix * g.C + c0, v);
+  for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL) {
+    float v[DFINE_NA_UNROLL][VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      acc[0][i] += v[i];
-      acc[1][i] += v[i] * v[i];
+    for (int u = 0; u < DFINE_NA_UNROLL; ++u) {
+      const int pix = first + (n + u) * blockDim.y;
+      if (n + u < g.pix_per_thread && pix < g.n_pix) {
+        load_vec<T, VEC>(x + (size_t)pix * g.C + c0, v[u]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[u][i] = 0.f;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < DFINE_NA_UNROLL; ++u)
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        acc[0][i] += v[u][i];
+        acc[1][i] += v[u][i] * v[u][i];
+      }
   }
   ColReduce<T, 2>::template run<VEC>(acc, red, sums, g.C, c0);
 }
 
-// mean / rstd of channel c from the fp64 sums (training) or the running statistics (eval)
-__device__ __forceinline__ void channel_stats(const double* sums, const float* running_mean,
-                                              const float* running_var, const NaGeom& g, int c,
-                                              float* mean, float* rstd, float* var_biased) {
-  if (g.training) {
-    const double m = sums[c] / g.n_pix;
-    double v = sums[g.C + c] / g.n_pix - m * m;
-    if (v < 0) v = 0;
-    *mean = (float)m;
-    *var_biased = (float)v;
-    *rstd = rsqrtf((float)v + g.eps);
-  } else {
-    *mean = running_mean[c];
-    *var_biased = running_var[c];
-    *rstd = rsqrtf(running_var[c] + g.eps);
-  }
-}
-
+// Forward apply. One thread per channel of the block's slice turns the fp64 sums (training) or the
+// running statistics (eval) into scale/shift in LDS; block row 0 also keeps the books.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const T* __restrict__ x, const T* __restrict__ addend, T* __restrict__ y,
     const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ save_mean,
     float* __restrict__ save_rstd, const float* __restrict__ lab_scale, const float* __restrict__ lab_bias, NaGeom g) {
-  const int c0 = (blockIdx.y * blockDim.x + threadIdx.x) * VEC;
+  extern __shared__ __attribute__((aligned(16))) float cst[];
+  const int lanes = blockDim.x * VEC;
+  const int cbase = blockIdx.y * lanes;
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  for (int k = tid; k < lanes; k += blockDim.x * blockDim.y) {
+    const int c = cbase + k;
+    float mean, rstd;
+    if (g.training) {
+      const double m = sums[c] / g.n_pix;
+      double v = sums[g.C + c] / g.n_pix - m * m;
+      if (v < 0) v = 0;
+      mean = (float)m;
+      const float var = (float)v;
+      rstd = rsqrtf(var + g.eps);
+      if (blockIdx.x == 0) {
+        save_mean[c] = mean;
+        save_rstd[c] = rstd;
+        const float unbiased = g.n_pix > 1 ? var * ((float)g.n_pix / (float)(g.n_pix - 1)) : var;
+        running_mean[c] = (1.f - g.momentum) * running_mean[c] + g.momentum * mean;
+        running_var[c] = (1.f - g.momentum) * running_var[c] + g.momentum * unbiased;
+      }
+    } else {
+      mean = running_mean[c];
+      rstd = rsqrtf(running_var[c] + g.eps);
+    }
+    const float sc = rstd * gamma[c];
+    cst[k] = sc;
+    cst[lanes + k] = beta[c] - mean * sc;
+  }
+  __syncthreads();
+  const int c0 = cbase + threadIdx.x * VEC;
   float scale[VEC], shift[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    float mean, rstd, var;
-    channel_stats(sums, running_mean, running_var, g, c0 + i, &mean, &rstd, &var);
-    scale[i] = rstd * gamma[c0 + i];
-    shift[i] = beta[c0 + i] - mean * scale[i];
-    if (g.training && blockIdx.x == 0 && threadIdx.y == 0) {  // one thread per channel keeps the books
-      save_mean[c0 + i] = mean;
-      save_rstd[c0 + i] = rstd;
-      const float unbiased = g.n_pix > 1 ? var * ((float)g.n_pix / (float)(g.n_pix - 1)) : var;
-      running_mean[c0 + i] = (1.f - g.momentum) * running_mean[c0 + i] + g.momentum * mean;
-      running_var[c0 + i] = (1.f - g.momentum) * running_var[c0 + i] + g.momentum * unbiased;
-    }
+    scale[i] = cst[threadIdx.x * VEC + i];
+    shift[i] = cst[lanes + threadIdx.x * VEC + i];
   }
   const float ls = g.has_lab ? lab_scale[0] : 1.f, lb = g.has_lab ? lab_bias[0] : 0.f;
   const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
-  for (int n = 0; n < g.pix_per_thread; ++n) {
-    const int pix = first + n * blockDim.y;
-    if (pix >= g.n_pix) break;
-    const size_t off = (size_t)pix * g.C + c0;
-    float v[VEC], a[VEC];
-    load_vec<T, VEC>(x + off, v);
-    if (g.has_add) load_vec<T, VEC>(addend + off, a);
+  for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL) {
+    float v[DFINE_NA_UNROLL][VEC], a[DFINE_NA_UNROLL][VEC];
+    bool ok[DFINE_NA_UNROLL];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      float z = v[i] * scale[i] + shift[i];
-      if (g.has_add) z += a[i];
-      v[i] = ls * act_fwd(z, g.act) + lb;
+    for (int u = 0; u < DFINE_NA_UNROLL; ++u) {
+      const int pix = first + (n + u) * blockDim.y;
+      ok[u] = n + u < g.pix_per_thread && pix < g.n_pix;
+      if (ok[u]) {
+        const size_t off = (size_t)pix * g.C + c0;
+        load_vec<T, VEC>(x + off, v[u]);
+        if (g.has_add) load_vec<T, VEC>(addend + off, a[u]);
+      }
     }
-    store_vec<T, VEC>(y + off, v);
+#pragma unroll
+    for (int u = 0; u < DFINE_NA_UNROLL; ++u) {
+      if (!ok[u]) continue;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float z = v[u][i] * scale[i] + shift[i];
+        if (g.has_add) z += a[u][i];
+        v[u][i] = ls * act_fwd(z, g.act) + lb;
+      }
+      store_vec<T, VEC>(y + (size_t)(first + (n + u) * blockDim.y) * g.C + c0, v[u]);
+    }
   }
 }
 
@@ -154,15 +183,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ lab_scale,
     double* __restrict__ red_out, NaGeom g) {
   extern __shared__ __attribute__((aligned(16))) float red[];
-  const int c0 = (blockIdx.y * blockDim.x + threadIdx.x) * VEC;
+  const int lanes = blockDim.x * VEC;
+  const int cbase = blockIdx.y * lanes;
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  for (int k = tid; k < lanes; k += blockDim.x * blockDim.y) {
+    const int c = cbase + k;
+    red[k] = save_mean[c];
+    red[lanes + k] = save_rstd[c];
+    red[2 * lanes + k] = gamma[c];
+    red[3 * lanes + k] = beta[c];
+  }
+  __syncthreads();
+  const int c0 = cbase + threadIdx.x * VEC;
   float mean[VEC], rstd[VEC], gam[VEC], bet[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    mean[i] = save_mean[c0 + i];
-    rstd[i] = save_rstd[c0 + i];
-    gam[i] = gamma[c0 + i];
-    bet[i] = beta[c0 + i];
+    const int k = threadIdx.x * VEC + i;
+    mean[i] = red[k];
+    rstd[i] = red[lanes + k];
+    gam[i] = red[2 * lanes + k];
+    bet[i] = red[3 * lanes + k];
   }
+  __syncthreads();  // `red` is reused by the column reduction below
   const float ls = g.has_lab ? lab_scale[0] : 1.f;
   float acc[4][VEC];
 #pragma unroll
@@ -170,24 +212,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[q][i] = 0.f;
   const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
-  for (int n = 0; n < g.pix_per_thread; ++n) {
-    const int pix = first + n * blockDim.y;
-    if (pix >= g.n_pix) break;
-    const size_t off = (size_t)pix * g.C + c0;
-    float v[VEC], a[VEC], d[VEC];
-    load_vec<T, VEC>(x + off, v);
-    load_vec<T, VEC>(dy + off, d);
-    if (g.has_add) load_vec<T, VEC>(addend + off, a);
+  for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL) {
+    float v[DFINE_NA_UNROLL][VEC], a[DFINE_NA_UNROLL][VEC], d[DFINE_NA_UNROLL][VEC];
+    bool ok[DFINE_NA_UNROLL];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      const float xhat = (v[i] - mean[i]) * rstd[i];
-      float z = xhat * gam[i] + bet[i];
-      if (g.has_add) z += a[i];
-      const float dz = d[i] * ls * act_grad(z, g.act);
-      acc[0][i] += dz;
-      acc[1][i] += dz * xhat;
-      acc[2][i] += d[i] * act_fwd(z, g.act);
-      acc[3][i] += d[i];
+    for (int u = 0; u < DFINE_NA_UNROLL; ++u) {
+      const int pix = first + (n + u) * blockDim.y;
+      ok[u] = n + u < g.pix_per_thread && pix < g.n_pix;
+      if (ok[u]) {
+        const size_t off = (size_t)pix * g.C + c0;
+        load_vec<T, VEC>(x + off, v[u]);
+        load_vec<T, VEC>(dy + off, d[u]);
+        if (g.has_add) load_vec<T, VEC>(addend + off, a[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < DFINE_NA_UNROLL; ++u) {
+      if (!ok[u]) continue;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float xhat = (v[u][i] - mean[i]) * rstd[i];
+        float z = xhat * gam[i] + bet[i];
+        if (g.has_add) z += a[u][i];
+        const float dz = d[u][i] * ls * act_grad(z, g.act);
+        acc[0][i] += dz;
+        acc[1][i] += dz * xhat;
+        acc[2][i] += d[u][i] * act_fwd(z, g.act);
+        acc[3][i] += d[u][i];
+      }
     }
   }
   ColReduce<T, 4>::template run<VEC>(acc, red, red_out, g.C, c0);
@@ -202,52 +254,74 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ lab_scale,
     const double* __restrict__ red_in, T* __restrict__ dx, T* __restrict__ dadd,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dlab, NaGeom g) {
-  const int c0 = (blockIdx.y * blockDim.x + threadIdx.x) * VEC;
-  float mean[VEC], rstd[VEC], gam[VEC], bet[VEC], m_dz[VEC], m_dzx[VEC];
-  float lab_s = 0.f, lab_b = 0.f;
+  extern __shared__ __attribute__((aligned(16))) float cst[];
+  const int lanes = blockDim.x * VEC;
+  const int cbase = blockIdx.y * lanes;
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
   const float inv_n = 1.f / (float)g.n_pix;
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    const int c = c0 + i;
-    mean[i] = save_mean[c];
-    rstd[i] = save_rstd[c];
-    gam[i] = gamma[c];
-    bet[i] = beta[c];
+  for (int k = tid; k < lanes; k += blockDim.x * blockDim.y) {
+    const int c = cbase + k;
     const float s_dz = (float)red_in[c], s_dzx = (float)red_in[g.C + c];
-    m_dz[i] = g.training ? s_dz * inv_n : 0.f;   // eval-mode BN: statistics are constants
-    m_dzx[i] = g.training ? s_dzx * inv_n : 0.f;
-    if (blockIdx.x == 0 && threadIdx.y == 0) {
+    cst[k] = save_mean[c];
+    cst[lanes + k] = save_rstd[c];
+    cst[2 * lanes + k] = gamma[c];
+    cst[3 * lanes + k] = beta[c];
+    cst[4 * lanes + k] = g.training ? s_dz * inv_n : 0.f;  // eval-mode BN: statistics are constants
+    cst[5 * lanes + k] = g.training ? s_dzx * inv_n : 0.f;
+    if (blockIdx.x == 0) {
       dgamma[c] = s_dzx;
       dbeta[c] = s_dz;
-      lab_s += (float)red_in[2 * g.C + c];
-      lab_b += (float)red_in[3 * g.C + c];
+      if (g.has_lab) {
+        atomicAdd(dlab, (float)red_in[2 * g.C + c]);
+        atomicAdd(dlab + 1, (float)red_in[3 * g.C + c]);
+      }
     }
   }
-  if (g.has_lab && blockIdx.x == 0 && threadIdx.y == 0) {
-    atomicAdd(dlab, lab_s);
-    atomicAdd(dlab + 1, lab_b);
+  __syncthreads();
+  const int c0 = cbase + threadIdx.x * VEC;
+  float mean[VEC], rstd[VEC], gam[VEC], bet[VEC], m_dz[VEC], m_dzx[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int k = threadIdx.x * VEC + i;
+    mean[i] = cst[k];
+    rstd[i] = cst[lanes + k];
+    gam[i] = cst[2 * lanes + k];
+    bet[i] = cst[3 * lanes + k];
+    m_dz[i] = cst[4 * lanes + k];
+    m_dzx[i] = cst[5 * lanes + k];
   }
   const float ls = g.has_lab ? lab_scale[0] : 1.f;
   const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
-  for (int n = 0; n < g.pix_per_thread; ++n) {
-    const int pix = first + n * blockDim.y;
-    if (pix >= g.n_pix) break;
-    const size_t off = (size_t)pix * g.C + c0;
-    float v[VEC], a[VEC], d[VEC];
-    load_vec<T, VEC>(x + off, v);
-    load_vec<T, VEC>(dy + off, d);
-    if (g.has_add) load_vec<T, VEC>(addend + off, a);
+  for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL) {
+    float v[DFINE_NA_UNROLL][VEC], a[DFINE_NA_UNROLL][VEC], d[DFINE_NA_UNROLL][VEC];
+    bool ok[DFINE_NA_UNROLL];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      const float xhat = (v[i] - mean[i]) * rstd[i];
-      float z = xhat * gam[i] + bet[i];
-      if (g.has_add) z += a[i];
-      const float dz = d[i] * ls * act_grad(z, g.act);
-      a[i] = dz;
-      v[i] = gam[i] * rstd[i] * (dz - m_dz[i] - xhat * m_dzx[i]);
+    for (int u = 0; u < DFINE_NA_UNROLL; ++u) {
+      const int pix = first + (n + u) * blockDim.y;
+      ok[u] = n + u < g.pix_per_thread && pix < g.n_pix;
+      if (ok[u]) {
+        const size_t off = (size_t)pix * g.C + c0;
+        load_vec<T, VEC>(x + off, v[u]);
+        load_vec<T, VEC>(dy + off, d[u]);
+        if (g.has_add) load_vec<T, VEC>(addend + off, a[u]);
+      }
     }
-    store_vec<T, VEC>(dx + off, v);
-    if (g.has_add) store_vec<T, VEC>(dadd + off, a);
+#pragma unroll
+    for (int u = 0; u < DFINE_NA_UNROLL; ++u) {
+      if (!ok[u]) continue;
+      const size_t off = (size_t)(first + (n + u) * blockDim.y) * g.C + c0;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float xhat = (v[u][i] - mean[i]) * rstd[i];
+        float z = xhat * gam[i] + bet[i];
+        if (g.has_add) z += a[u][i];
+        const float dz = d[u][i] * ls * act_grad(z, g.act);
+        a[u][i] = dz;
+        v[u][i] = gam[i] * rstd[i] * (dz - m_dz[i] - xhat * m_dzx[i]);
+      }
+      store_vec<T, VEC>(dx + off, v[u]);
+      if (g.has_add) store_vec<T, VEC>(dadd + off, a[u]);
+    }
   }
 }
 
@@ -287,7 +361,7 @@ static int fwd_impl(const void* x, const void* addend, void* y, double* sums, co
                     const float* lab_bias, int n_pix, int C, int act, int training, float eps, float momentum, hipStream_t st) {
   NaLaunch R, A;
   if (int rc = plan<VEC>(&R, n_pix, C, 512)) return rc;   // reductions: few blocks -> few contended atomics
-  if (int rc = plan<VEC>(&A, n_pix, C, 2048)) return rc;  // streaming: fill the chip
+  if (int rc = plan<VEC>(&A, n_pix, C, 1024)) return rc;  // streaming: ~4 blocks per CU, several pixels per thread
   if (training) {
     NaGeom g = make_geom(n_pix, C, R.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, momentum);
     const size_t lds = (size_t)R.block.y * 2 * R.block.x * VEC * sizeof(float);
@@ -295,7 +369,7 @@ static int fwd_impl(const void* x, const void* addend, void* y, double* sums, co
     DFINE_LAUNCH_CHECK();
   }
   NaGeom g = make_geom(n_pix, C, A.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, momentum);
-  hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), A.grid, A.block, 0, st, (const T*)x, (const T*)addend, (T*)y, sums, gamma, beta,
+  hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), A.grid, A.block, (size_t)2 * A.block.x * VEC * sizeof(float), st, (const T*)x, (const T*)addend, (T*)y, sums, gamma, beta,
                      running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, g);
   DFINE_LAUNCH_CHECK();
   return 0;
@@ -308,14 +382,14 @@ static int bwd_impl(const void* x, const void* addend, const void* dy, const flo
                     hipStream_t st) {
   NaLaunch R, A;
   if (int rc = plan<VEC>(&R, n_pix, C, 512)) return rc;
-  if (int rc = plan<VEC>(&A, n_pix, C, 2048)) return rc;
+  if (int rc = plan<VEC>(&A, n_pix, C, 1024)) return rc;
   NaGeom g = make_geom(n_pix, C, R.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, 0.f);
   const size_t lds = (size_t)R.block.y * 4 * R.block.x * VEC * sizeof(float);
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy,
                      save_mean, save_rstd, gamma, beta, lab_scale, red, g);
   DFINE_LAUNCH_CHECK();
   g.pix_per_thread = A.ppt;
-  hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VEC>), A.grid, A.block, 0, st, (const T*)x, (const T*)addend, (const T*)dy, save_mean,
+  hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VEC>), A.grid, A.block, (size_t)6 * A.block.x * VEC * sizeof(float), st, (const T*)x, (const T*)addend, (const T*)dy, save_mean,
                      save_rstd, gamma, beta, lab_scale, red, (T*)dx, (T*)dadd, dgamma, dbeta, dlab, g);
   DFINE_LAUNCH_CHECK();
   return 0;
