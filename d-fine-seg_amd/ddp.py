@@ -71,6 +71,9 @@ class BucketedGradReducer:
     def __init__(self, model, num_buckets=4, process_group=None, broadcast_parameters=True):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("BucketedGradReducer needs an initialised process group")
+        from . import ops
+
+        ops.DIRECT_WGRAD_ACCUM = False  # bucket completion is counted from autograd's accumulate hooks
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.flat = model if isinstance(model, FlatState) else FlatState(model)

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .configs import ModelSpec
-from .layers import MLP, ConvNorm, PackedSelfAttention, bias_for_prior
+from .layers import MLP, ConvNorm, Linear, PackedSelfAttention, bias_for_prior
 from .targets import TargetBatch
 
 
@@ -57,8 +57,8 @@ class MSDeformableAttention(nn.Module):
         super().__init__()
         self.n_head, self.num_points = n_head, list(num_points)
         P = sum(num_points)
-        self.sampling_offsets = nn.Linear(dim, n_head * P * 2)
-        self.attention_weights = nn.Linear(dim, n_head * P)
+        self.sampling_offsets = Linear(dim, n_head * P * 2)
+        self.attention_weights = Linear(dim, n_head * P)
         self.register_buffer("num_points_scale", torch.tensor([1.0 / n for n in num_points for _ in range(n)]))
         self._reset()
 
@@ -88,7 +88,7 @@ class MSDeformableAttention(nn.Module):
 class Gate(nn.Module):
     def __init__(self, dim):
         super().__init__()
-        self.gate = nn.Linear(2 * dim, 2 * dim)
+        self.gate = Linear(2 * dim, 2 * dim)
         nn.init.constant_(self.gate.bias, bias_for_prior(0.5))
         nn.init.zeros_(self.gate.weight)
         self.norm = nn.LayerNorm(dim)
@@ -105,8 +105,8 @@ class DecoderLayer(nn.Module):
         self.norm1 = nn.LayerNorm(dim)
         self.cross_attn = MSDeformableAttention(dim, n_head, num_points)
         self.gateway = Gate(dim)
-        self.linear1 = nn.Linear(dim, ffn)
-        self.linear2 = nn.Linear(ffn, dim)
+        self.linear1 = Linear(dim, ffn)
+        self.linear2 = Linear(ffn, dim)
         self.norm3 = nn.LayerNorm(dim)
         nn.init.xavier_uniform_(self.linear1.weight)
         nn.init.xavier_uniform_(self.linear2.weight)
@@ -192,11 +192,11 @@ class DFINETransformer(nn.Module):
             self.mask_head = MLP(hid, hid, spec.mask_dim, 3)
         self.query_pos_head = MLP(4, 2 * hid, hid, 2)
         self.enc_output = nn.Sequential()
-        self.enc_output.add_module("proj", nn.Linear(hid, hid))
+        self.enc_output.add_module("proj", Linear(hid, hid))
         self.enc_output.add_module("norm", nn.LayerNorm(hid))
-        self.enc_score_head = nn.Linear(hid, num_classes)
+        self.enc_score_head = Linear(hid, num_classes)
         self.enc_bbox_head = MLP(hid, hid, 4, 3)
-        self.dec_score_head = nn.ModuleList(nn.Linear(hid, num_classes) for _ in range(spec.num_layers))
+        self.dec_score_head = nn.ModuleList(Linear(hid, num_classes) for _ in range(spec.num_layers))
         self.pre_bbox_head = MLP(hid, hid, 4, 3)
         self.dec_bbox_head = nn.ModuleList(MLP(hid, hid, 4 * (spec.reg_max + 1), 3) for _ in range(spec.num_layers))
         if eval_spatial_size:  # buffers in the checkpoint layout (:700-706)

@@ -7,7 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .configs import ModelSpec
-from .layers import ConvNorm, PackedSelfAttention
+from .layers import ConvNorm, Linear, PackedSelfAttention
 
 
 class RepVgg(nn.Module):
@@ -68,8 +68,8 @@ class EncoderLayer(nn.Module):
     def __init__(self, dim, n_head, ffn):
         super().__init__()
         self.self_attn = PackedSelfAttention(dim, n_head)
-        self.linear1 = nn.Linear(dim, ffn)
-        self.linear2 = nn.Linear(ffn, dim)
+        self.linear1 = Linear(dim, ffn)
+        self.linear2 = Linear(ffn, dim)
         self.norm1 = nn.LayerNorm(dim)
         self.norm2 = nn.LayerNorm(dim)
 

@@ -105,13 +105,21 @@ class ConvNorm(nn.Module):
         self._pending_batches = 0
 
 
+class Linear(nn.Linear):
+    """nn.Linear (same parameters / state_dict keys) whose bf16 training path goes through
+    ``ops.linear``: library GEMMs for y and dx, the HIP split-M kernel for dW / db."""
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
 class MLP(nn.Module):
     """Linear stack with ReLU in between (dfine_decoder.py:33-46); keys ``layers.{i}``."""
 
     def __init__(self, d_in, d_hidden, d_out, n_layers):
         super().__init__()
         dims = [d_in] + [d_hidden] * (n_layers - 1) + [d_out]
-        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.layers = nn.ModuleList(Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
@@ -132,7 +140,7 @@ class PackedSelfAttention(nn.Module):
         self.dim, self.n_head = dim, n_head
         self.in_proj_weight = nn.Parameter(torch.empty(3 * dim, dim))
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * dim))
-        self.out_proj = nn.Linear(dim, dim)
+        self.out_proj = Linear(dim, dim)
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.zeros_(self.out_proj.bias)
 
@@ -140,8 +148,8 @@ class PackedSelfAttention(nn.Module):
         """qk_in, v_in: [B, L, D]; blocked: optional bool [L, L], True = may NOT attend."""
         B, L, D = qk_in.shape
         H, dh = self.n_head, D // self.n_head
-        qk = F.linear(qk_in, self.in_proj_weight[: 2 * D], self.in_proj_bias[: 2 * D])
-        v = F.linear(v_in, self.in_proj_weight[2 * D :], self.in_proj_bias[2 * D :])
+        qk = ops.linear(qk_in, self.in_proj_weight, self.in_proj_bias, 0, 2 * D)
+        v = ops.linear(v_in, self.in_proj_weight, self.in_proj_bias, 2 * D, 3 * D)
         q, k = qk.view(B, L, 2, H, dh).permute(2, 0, 3, 1, 4)
         v = v.view(B, L, H, dh).transpose(1, 2)
         allowed = None if blocked is None else ~blocked

@@ -362,3 +362,72 @@ def criterion_head(logits, boxes, corners, ref_points, teacher_corners, teacher_
                                 own_assign.contiguous(), go_assign.contiguous(), tgt_labels.contiguous(),
                                 tgt_boxes.contiguous(), Wn, scalars, float(alpha), float(gamma), float(reg_scale),
                                 float(temperature))
+
+
+# Accumulate Linear weight gradients straight into ``param.grad`` (the flat fp32 gradient buffer) and
+# hand autograd ``None`` for them -- the same contract as a fused wgrad-accumulate GEMM. Switched off
+# by the data-parallel reducer, which counts post-accumulate hooks to know when a bucket is complete.
+DIRECT_WGRAD_ACCUM = True
+
+
+class _Linear(torch.autograd.Function):
+    """y = x @ W[rows]^T + b[rows] in bf16 (hipBLASLt), with the weight/bias gradient by the split-M
+    MFMA kernel dfine_linear_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, row_begin, row_end):
+        w = weight[row_begin:row_end]
+        b = bias[row_begin:row_end] if bias is not None else None
+        x16 = x.to(torch.bfloat16)
+        w16 = w.to(torch.bfloat16)
+        y = torch.nn.functional.linear(x16, w16, b.to(torch.bfloat16) if b is not None else None)
+        ctx.save_for_backward(x16, w16)
+        ctx.params = (weight, bias, row_begin, row_end)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x16, w16 = ctx.saved_tensors
+        weight, bias, r0, r1 = ctx.params
+        lib = _lib.load()
+        N, K = w16.shape
+        gy16 = gy.to(torch.bfloat16).reshape(-1, N)
+        if not gy16.is_contiguous():
+            gy16 = gy16.contiguous()
+        x2 = x16.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        dx = (gy16 @ w16).view_as(x16) if ctx.needs_input_grad[0] else None
+        direct = (DIRECT_WGRAD_ACCUM and weight.grad is not None and weight.grad.dtype == torch.float32
+                  and weight.grad.is_contiguous() and (bias is None or (bias.grad is not None and bias.grad.is_contiguous())))
+        if direct:
+            dw, db = weight.grad[r0:r1], (bias.grad[r0:r1] if bias is not None else None)
+        else:
+            dw = torch.zeros(N, K, dtype=torch.float32, device=x16.device)
+            db = torch.zeros(N, dtype=torch.float32, device=x16.device) if bias is not None else None
+        with _lib.timed("linear_wgrad", (M * N + M * K) * 2 + N * K * 4):
+            rc = lib.dfine_linear_wgrad(_lib.ptr(gy16), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), M, N, K, K, _lib.stream_ptr())
+        _lib.check(rc, "dfine_linear_wgrad")
+        if direct:
+            return dx, None, None, None, None
+        full_w = dw if (r0 == 0 and r1 == weight.shape[0]) else torch.zeros_like(weight, dtype=torch.float32).index_put_((torch.arange(r0, r1, device=dw.device),), dw)
+        full_b = None
+        if bias is not None:
+            full_b = db if (r0 == 0 and r1 == bias.shape[0]) else torch.zeros_like(bias, dtype=torch.float32).index_put_((torch.arange(r0, r1, device=db.device),), db)
+        return dx, full_w.to(weight.dtype), (full_b.to(bias.dtype) if full_b is not None else None), None, None
+
+
+def linear(x, weight, bias=None, row_begin=0, row_end=None):
+    """``F.linear(x, weight[row_begin:row_end], bias[row_begin:row_end])``. On the GPU in bf16 mode
+    (autocast, or bf16 input) the forward and the input gradient are library GEMMs and the weight/bias
+    gradient is the split-M HIP kernel; otherwise (fp32 parity runs, shapes with N or K not a multiple
+    of 8) it is plain ``F.linear``."""
+    row_end = weight.shape[0] if row_end is None else row_end
+    n, k = row_end - row_begin, weight.shape[1]
+    bf16_mode = x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16)
+    if not bf16_mode or n % 8 or k % 8 or not (weight.requires_grad and torch.is_grad_enabled()):
+        w = weight if (row_begin == 0 and row_end == weight.shape[0]) else weight[row_begin:row_end]
+        b = bias if (bias is None or (row_begin == 0 and row_end == weight.shape[0])) else bias[row_begin:row_end]
+        return torch.nn.functional.linear(x, w, b)
+    return _Linear.apply(x, weight, bias, row_begin, row_end)

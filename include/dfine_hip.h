@@ -201,6 +201,18 @@ int dfine_criterion_head(const void* logits, int logits_dtype, const float* boxe
                          float* d_corners_ddf, int B, int Q, int C, int G, int n_bins, float alpha, float gamma,
                          float reg_scale, float temperature, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Weight/bias gradient of y = x @ W^T + b (autograd of F.linear / nn.Linear, used by every
+ * projection and MLP of the decoder and the AIFI layer: src/d_fine/arch/dfine_decoder.py:33-46,
+ * 181-271; hybrid_encoder.py:243-290), split over the token axis, bf16 MFMA, fp32 accumulation:
+ *     dW[n][k] += sum_m dY[m][n] * X[m][k]          db[n] += sum_m dY[m][n]   (db may be NULL)
+ *   dY [M, N] bf16, X [M, K] bf16 (row-major); dW f32 rows of length K with leading dimension ldw
+ *   (>= K), db f32 [N]. Both are ACCUMULATED with float atomics: point them at the fp32 gradient
+ *   buffer itself (or at zeroed scratch). Needs N % 8 == 0 and K % 8 == 0.
+ * ------------------------------------------------------------------------------------- */
+int dfine_linear_wgrad(const void* dY, const void* X, float* dW, float* db, int M, int N, int K, int ldw,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif
