@@ -21,7 +21,7 @@ def test_linear_wgrad_matches_fp32_reference(hip_lib, M, N, K):
     ref_w = dy.float().t() @ x.float()
     ref_b = dy.float().sum(0)
     # exact bf16 products, fp32 sums in a different order (MFMA blocks + atomics): error ~ sqrt(M) * eps
-    tol = 2e-6 * M**0.5 + 1e-4
+    tol = 3e-8 * M + 2e-4  # fp32 round-off of a length-M sum of O(1) terms
     torch.testing.assert_close(dw, ref_w, rtol=1e-4, atol=tol * 4)
     torch.testing.assert_close(db, ref_b, rtol=1e-4, atol=tol * 4)
     # accumulation semantics: a second call adds on top
