@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
     const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ lab_scale,
     const double* __restrict__ red_in, T* __restrict__ dx, T* __restrict__ dadd,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dlab, NaGeom g) {
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dlab_scale, float* __restrict__ dlab_bias,
+    NaGeom g) {
   extern __shared__ __attribute__((aligned(16))) float cst[];
   const int lanes = blockDim.x * VEC;
   const int cbase = blockIdx.y * lanes;
@@ -268,12 +269,12 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
     cst[3 * lanes + k] = beta[c];
     cst[4 * lanes + k] = g.training ? s_dz * inv_n : 0.f;  // eval-mode BN: statistics are constants
     cst[5 * lanes + k] = g.training ? s_dzx * inv_n : 0.f;
-    if (blockIdx.x == 0) {
-      dgamma[c] = s_dzx;
-      dbeta[c] = s_dz;
+    if (blockIdx.x == 0) {  // one writer per channel: accumulate (the caller may point these at .grad)
+      dgamma[c] += s_dzx;
+      dbeta[c] += s_dz;
       if (g.has_lab) {
-        atomicAdd(dlab, (float)red_in[2 * g.C + c]);
-        atomicAdd(dlab + 1, (float)red_in[3 * g.C + c]);
+        atomicAdd(dlab_scale, (float)red_in[2 * g.C + c]);
+        atomicAdd(dlab_bias, (float)red_in[3 * g.C + c]);
       }
     }
   }
@@ -378,8 +379,8 @@ static int fwd_impl(const void* x, const void* addend, void* y, double* sums, co
 template <typename T, int VEC>
 static int bwd_impl(const void* x, const void* addend, const void* dy, const float* save_mean, const float* save_rstd,
                     const float* gamma, const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
-                    float* dgamma, float* dbeta, float* dlab, int n_pix, int C, int act, int training, float eps,
-                    hipStream_t st) {
+                    float* dgamma, float* dbeta, float* dlab_scale, float* dlab_bias, int n_pix, int C, int act, int training,
+                    float eps, hipStream_t st) {
   NaLaunch R, A;
   if (int rc = plan<VEC>(&R, n_pix, C, 512)) return rc;
   if (int rc = plan<VEC>(&A, n_pix, C, 1024)) return rc;
@@ -390,7 +391,7 @@ static int bwd_impl(const void* x, const void* addend, const void* dy, const flo
   DFINE_LAUNCH_CHECK();
   g.pix_per_thread = A.ppt;
   hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VEC>), A.grid, A.block, (size_t)6 * A.block.x * VEC * sizeof(float), st, (const T*)x, (const T*)addend, (const T*)dy, save_mean,
-                     save_rstd, gamma, beta, lab_scale, red, (T*)dx, (T*)dadd, dgamma, dbeta, dlab, g);
+                     save_rstd, gamma, beta, lab_scale, red, (T*)dx, (T*)dadd, dgamma, dbeta, dlab_scale, dlab_bias, g);
   DFINE_LAUNCH_CHECK();
   return 0;
 }
@@ -434,14 +435,14 @@ extern "C" int dfine_bn_act_fwd(const void* x, const void* addend, void* y, int 
 extern "C" int dfine_bn_act_bwd(const void* x, const void* addend, const void* dy, int dtype,
                                 const float* save_mean, const float* save_rstd, const float* gamma,
                                 const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
-                                float* dgamma, float* dbeta, float* dlab, int n_pix, int C, int act,
-                                int training, float eps, void* stream) {
+                                float* dgamma, float* dbeta, float* dlab_scale, float* dlab_bias, int n_pix,
+                                int C, int act, int training, float eps, void* stream) {
   if (!x || !dy || !save_mean || !save_rstd || !gamma || !beta || !red || !dx || !dgamma || !dbeta) return DFINE_E_BADARG;
   if ((addend != nullptr) != (dadd != nullptr)) return DFINE_E_BADARG;
-  if (lab_scale && !dlab) return DFINE_E_BADARG;
+  if (lab_scale && (!dlab_scale || !dlab_bias)) return DFINE_E_BADARG;
   if (n_pix <= 0 || C <= 0 || act < 0 || act > 2) return DFINE_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-#define BWD(T, V) bwd_impl<T, V>(x, addend, dy, save_mean, save_rstd, gamma, beta, lab_scale, red, dx, dadd, dgamma, dbeta, dlab, n_pix, C, act, training, eps, st)
+#define BWD(T, V) bwd_impl<T, V>(x, addend, dy, save_mean, save_rstd, gamma, beta, lab_scale, red, dx, dadd, dgamma, dbeta, dlab_scale, dlab_bias, n_pix, C, act, training, eps, st)
   DFINE_NA_DISPATCH(BWD);
 #undef BWD
 }

@@ -20,6 +20,44 @@ def msda_algorithmic_bytes(B, Lq, nH, P, c, elem):
     return corners * elem + side + io, corners * elem + side + io + corners * 4 + side
 
 
+class ZeroArena:
+    """Pre-zeroed fp32 scratch handed out in slices: the fused ops need ~300 small zero-initialised
+    workspaces per step (fp64 sum buffers, loss accumulators); one memset of the arena at the start of
+    the step replaces one fill launch per workspace. ``ops.zero_arena`` is None unless a training loop
+    installs one; without it every workspace is its own ``torch.zeros``."""
+
+    def __init__(self, numel, device):
+        self.buf = torch.zeros(numel, dtype=torch.float32, device=device)
+        self.used = 0
+        self.high_water = 0
+
+    def reset(self):
+        """Zero what the previous step touched and start handing out from the beginning."""
+        if self.used:
+            self.buf[: self.used].zero_()
+        self.high_water = max(self.high_water, self.used)
+        self.used = 0
+
+    def take(self, n):
+        n = (n + 3) // 4 * 4  # keep 16-byte alignment (fp64 views)
+        if self.used + n > self.buf.numel():
+            return None
+        out = self.buf[self.used : self.used + n]
+        self.used += n
+        return out
+
+
+zero_arena = None
+
+
+def zeros_f32(n, device):
+    if zero_arena is not None and zero_arena.buf.device == device:
+        out = zero_arena.take(n)
+        if out is not None:
+            return out[:n]
+    return torch.zeros(n, dtype=torch.float32, device=device)
+
+
 class _MSDeformAttnCore(torch.autograd.Function):
     """Gather behind decoder cross-attention; see include/dfine_hip.h (dfine_msda_fwd/bwd)."""
 
@@ -174,6 +212,7 @@ class _DepthwiseConv2d(torch.autograd.Function):
         _lib.check(rc, "dfine_dwconv_fwd")
         ctx.save_for_backward(xl, w)
         ctx.cfg = (stride, k, weight.dtype)
+        ctx.weight = weight
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -195,7 +234,10 @@ class _DepthwiseConv2d(torch.autograd.Function):
             _lib.check(rc, "dfine_dwconv_bwd_data")
             dx = dx.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros(C, 1, k, k, dtype=torch.float32, device=xl.device)
+            wp = ctx.weight
+            direct = (DIRECT_WGRAD_ACCUM and wp.grad is not None and wp.grad.dtype == torch.float32
+                      and wp.grad.stride() == (k * k, k * k, k, 1))  # [C,1,k,k] laid out as C*k*k (channels_last with 1 channel)
+            dw = wp.grad if direct else torch.zeros(C, 1, k, k, dtype=torch.float32, device=xl.device)
             n_ws = lib.dfine_dwconv_bwd_weight_workspace(B, H, W, C, k, stride)
             if n_ws < 0:
                 raise _lib.DfineHipError(f"depthwise conv weight gradient: unsupported shape C={C} k={k} stride={stride}")
@@ -204,7 +246,7 @@ class _DepthwiseConv2d(torch.autograd.Function):
                 rc = lib.dfine_dwconv_bwd_weight(_lib.ptr(xl), _lib.ptr(gy), _lib.ptr(dw), _lib.ptr(ws), n_ws, code,
                                                  B, H, W, C, k, stride, st)
             _lib.check(rc, "dfine_dwconv_bwd_weight")
-            dw = dw.to(w_dtype)
+            dw = None if direct else dw.to(w_dtype)
         return dx, dw, None
 
 
@@ -239,7 +281,7 @@ class _BatchNormAct(torch.autograd.Function):
         n_pix = B * H * W
         y = torch.empty_like(xl)
         # one zeroed workspace: fp64 sums [2C] (as 4C floats) | save_mean [C] | save_rstd [C]
-        ws = torch.zeros(6 * C, dtype=torch.float32, device=x.device)
+        ws = zeros_f32(6 * C, x.device)
         sums, save_mean, save_rstd = ws[: 4 * C], ws[4 * C : 5 * C], ws[5 * C :]
         g32, b32 = gamma.detach().float(), beta.detach().float()
         ls32 = lab_scale.detach().float() if lab_scale is not None else None
@@ -253,6 +295,7 @@ class _BatchNormAct(torch.autograd.Function):
         _lib.check(rc, "dfine_bn_act_fwd")
         ctx.save_for_backward(xl, al, g32, b32, save_mean, save_rstd, ls32)
         ctx.cfg = (act, eps, int(training), gamma.dtype, lab_scale.dtype if lab_scale is not None else None)
+        ctx.params = (gamma, beta, lab_scale, lab_bias)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -267,16 +310,28 @@ class _BatchNormAct(torch.autograd.Function):
         dx = torch.empty_like(xl)
         dadd = torch.empty_like(xl) if al is not None else None
         # one zeroed workspace: fp64 reductions [4C] (as 8C floats) | dgamma [C] | dbeta [C] | dlab [2]
-        ws = torch.zeros(10 * C + 2, dtype=torch.float32, device=xl.device)
+        ws = zeros_f32(10 * C + 2, xl.device)
         red, dgamma, dbeta, dlab = ws[: 8 * C], ws[8 * C : 9 * C], ws[9 * C : 10 * C], ws[10 * C :]
+        gamma_p, beta_p, ls_p, lb_p = ctx.params
+        plist = [gamma_p, beta_p] + ([ls_p, lb_p] if ls32 is not None else [])
+        direct = DIRECT_WGRAD_ACCUM and all(
+            p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in plist)
+        dls, dlb = dlab[0:1], dlab[1:2]
+        if direct:  # accumulate straight into the fp32 .grad views (no AccumulateGrad add kernels)
+            dgamma, dbeta = gamma_p.grad, beta_p.grad
+            if ls32 is not None:
+                dls, dlb = ls_p.grad, lb_p.grad
         nbytes = (2 * xl.numel() + 3 * gy.numel() + (2 * al.numel() if al is not None else 0)) * xl.element_size()
         with _lib.timed("bn_act_bwd", nbytes):
             rc = lib.dfine_bn_act_bwd(_lib.ptr(xl), _lib.ptr(al), _lib.ptr(gy), _lib.dtype_code(xl), _lib.ptr(save_mean),
                                       _lib.ptr(save_rstd), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(ls32), _lib.ptr(red),
                                       _lib.ptr(dx), _lib.ptr(dadd), _lib.ptr(dgamma), _lib.ptr(dbeta),
-                                      _lib.ptr(dlab) if ls32 is not None else None, n_pix, C, _ACT_CODES[act],
+                                      _lib.ptr(dls) if ls32 is not None else None,
+                                      _lib.ptr(dlb) if ls32 is not None else None, n_pix, C, _ACT_CODES[act],
                                       training, eps, _lib.stream_ptr())
         _lib.check(rc, "dfine_bn_act_bwd")
+        if direct:
+            return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None) + (None,) * 10
         return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None,
                 dgamma.to(g_dtype), dbeta.to(g_dtype), None, None,
                 dlab[0:1].to(lab_dtype) if ls32 is not None else None,
@@ -322,7 +377,7 @@ class _CriterionHead(torch.autograd.Function):
         if has_ddf:
             teacher_corners = teacher_corners.float().contiguous()
             teacher_logits = teacher_logits.to(logits.dtype).contiguous()
-        terms = torch.zeros(5, dtype=torch.float32, device=dev)
+        terms = zeros_f32(5, dev)
         d_logits = torch.empty_like(logits)
         d_l1 = torch.empty(B, Q, 4, dtype=torch.float32, device=dev)
         d_giou = torch.empty_like(d_l1)

@@ -30,9 +30,24 @@ class ModelEMA:
         for p in self.model.parameters():
             p.requires_grad_(False)
         self.momentum = momentum
-        src = dict(model.named_buffers())
-        pairs = [(b, src[k]) for k, b in self.model.named_buffers() if b.dtype.is_floating_point]
-        self._ema_bufs, self._cur_bufs = [a for a, _ in pairs], [b for _, b in pairs]
+        # float buffers of both models are re-homed into two flat tensors (views keep their shapes), so
+        # the buffer EMA is two launches instead of one per BatchNorm statistic
+        self._ema_flat = self._flatten([b for _, b in self.model.named_buffers() if b.dtype.is_floating_point])
+        self._cur_flat = self._flatten([b for _, b in model.named_buffers() if b.dtype.is_floating_point])
+
+    @staticmethod
+    def _flatten(tensors):
+        if not tensors:
+            return None
+        flat = torch.empty(sum(t.numel() for t in tensors), dtype=torch.float32, device=tensors[0].device)
+        off = 0
+        with torch.no_grad():
+            for t in tensors:
+                home = flat[off : off + t.numel()].view(t.shape)
+                home.copy_(t)
+                t.data = home
+                off += t.numel()
+        return flat
 
     def decay(self, iters):
         return self.momentum * (1 - math.exp(-iters / 2000))
@@ -40,12 +55,10 @@ class ModelEMA:
     def update_buffers(self, decay_tensor):
         """ema = decay*ema + (1-decay)*current for the float buffers; ``decay_tensor`` is a 0-dim device
         tensor so the same launches serve every step (mul/add form: anchors hold +inf, a lerp would NaN)."""
-        if not self._ema_bufs:
+        if self._ema_flat is None:
             return
         with torch.no_grad():
-            w = 1.0 - decay_tensor
-            torch._foreach_mul_(self._ema_bufs, decay_tensor)
-            torch._foreach_addcmul_(self._ema_bufs, self._cur_bufs, [w] * len(self._cur_bufs))
+            self._ema_flat.mul_(decay_tensor).addcmul_(self._cur_flat, 1.0 - decay_tensor)
 
 
 class TrainStep:
@@ -79,10 +92,18 @@ class TrainStep:
         self.graph_warmup = graph_warmup
         self._graphs = {}  # (batch, max_gt, has_gt) -> (graph, static images, static TargetBatch, static loss)
         self._conv_norms = [m for m in self.model.modules() if isinstance(m, ConvNorm)]
+        if self.device.type == "cuda":  # zero-initialised scratch for the fused ops: one memset per step
+            from . import ops
+
+            ops.zero_arena = ops.ZeroArena(4 << 20, self.device)
         self.model.train()
 
     # ------------------------------------------------------------------ one step, device side
     def _body(self, images, tb):
+        from . import ops
+
+        if ops.zero_arena is not None:
+            ops.zero_arena.reset()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
             out = self.model(images, targets=tb)
         losses = self.criterion(out)  # fp32, outside autocast like train.py:548-549

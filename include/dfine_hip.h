@@ -140,9 +140,10 @@ int dfine_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* wor
  * VGGBlock.forward (hybrid_encoder.py:115-121; `addend` = the other branch), forward and backward.
  *
  *   x, addend, y, dy, dx, dadd   [n_pix, C] (= [B,H,W,C]) bf16 or f32 (dtype); addend/dadd/lab_* may be NULL
- *   gamma, beta, running_mean, running_var, save_mean, save_rstd, dgamma, dbeta   f32 [C]
- *   lab_scale, lab_bias  f32 [1] each on the device (both or neither);  dlab f32 [2] =
- *       (d scale, d bias), ACCUMULATED (caller zeroes)
+ *   gamma, beta, running_mean, running_var, save_mean, save_rstd   f32 [C]
+ *   dgamma, dbeta f32 [C]: ACCUMULATED (+=; zeroed scratch or the parameters' fp32 .grad)
+ *   lab_scale, lab_bias  f32 [1] each on the device (both or neither);  dlab_scale, dlab_bias f32 [1]
+ *       each, ACCUMULATED (zeroed scratch or the parameters' fp32 .grad)
  *   sums f64 [2*C], red f64 [4*C]: workspaces, ZEROED by the caller before the call
  *   act: 0 identity, 1 ReLU, 2 SiLU.  training=1: batch statistics, running stats updated
  *   (momentum, unbiased variance); training=0 (forward only): running statistics.
@@ -155,8 +156,8 @@ int dfine_bn_act_fwd(const void* x, const void* addend, void* y, int dtype, doub
 int dfine_bn_act_bwd(const void* x, const void* addend, const void* dy, int dtype,
                      const float* save_mean, const float* save_rstd, const float* gamma,
                      const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
-                     float* dgamma, float* dbeta, float* dlab, int n_pix, int C, int act, int training,
-                     float eps, void* stream);
+                     float* dgamma, float* dbeta, float* dlab_scale, float* dlab_bias, int n_pix, int C,
+                     int act, int training, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Optimizer tail over FLAT fp32 buffers of n elements (all trainable parameters, grouped).
