@@ -102,21 +102,38 @@ def test_criterion_normaliser_allreduce_is_single_message():
     assert src.count("dist.all_reduce(") == 1
 
 
+_RCCL_SCRIPT = """
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+import dfine_seg_amd
+from dfine_seg_amd.ddp import BucketedGradReducer
+from dfine_seg_amd.synth import synthetic_batch
+from dfine_seg_amd.train import TrainStep
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT={port!r}, RANK="0", WORLD_SIZE="1")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+trainer = TrainStep("n", 80, False, (320, 320), "cuda", grad_reducer=BucketedGradReducer, total_steps=100)
+images, targets = synthetic_batch(2, 320, 320, 80, 4, seed=1, device="cuda")
+for _ in range(3):
+    loss = trainer.step(images, targets)
+assert torch.isfinite(loss)
+assert all(torch.isfinite(p).all() for p in trainer.model.parameters())
+assert float(trainer.flat.grads.abs().max()) == 0.0  # the fused optimizer zeroed the reduced gradients
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
 @pytest.mark.gpu
 def test_reducer_rccl_single_rank_train_step(hip_lib):
-    """The RCCL code path (backend "nccl", side stream, events) with a 1-rank group on the one GPU
-    of the test box: two full training steps of D-FINE-n must run and stay finite."""
-    from dfine_seg_amd.synth import synthetic_batch
-    from dfine_seg_amd.train import TrainStep
+    """The RCCL code path (backend "nccl", side stream, events, flat buckets) with a 1-rank group on the
+    one GPU of the test box: three full training steps of D-FINE-n must run and stay finite. Run the way
+    bench.py runs it -- a fresh process whose first act is init_process_group (the process group must
+    exist before autograd's device thread does; pytest's earlier GPU tests would have started it)."""
+    import subprocess
+    import sys
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        trainer = TrainStep("n", 80, False, (320, 320), "cuda", grad_reducer=BucketedGradReducer, total_steps=100)
-        images, targets = synthetic_batch(2, 320, 320, 80, 4, seed=1, device="cuda")
-        for _ in range(2):
-            loss = trainer.step(images, targets)
-        assert torch.isfinite(loss)
-        assert all(torch.isfinite(p).all() for p in trainer.model.parameters())
-    finally:
-        dist.destroy_process_group()
+    from conftest import ROOT
+
+    script = _RCCL_SCRIPT.format(root=ROOT, port=str(_free_port()))
+    proc = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0 and "RCCL_OK" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-4000:]
