@@ -27,12 +27,12 @@ SIGNATURES = {
     "dfine_dwconv_bwd_data": [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p],
     "dfine_dwconv_bwd_weight": [_c_void_p] * 4 + [ctypes.c_longlong] + [_c_int] * 7 + [_c_void_p],
     "dfine_dwconv_bwd_weight_workspace": [_c_int] * 6,
-    "dfine_bn_act_fwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 9 + [_c_int] * 4 + [ctypes.c_float] * 2 + [_c_void_p],
+    "dfine_bn_act_fwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 9 + [_c_int] * 4 + [ctypes.c_float] * 2 + [_c_int, _c_void_p],
     "dfine_criterion_head": [_c_void_p, _c_int] + [_c_void_p] * 17 + [_c_int] * 5 + [ctypes.c_float] * 4 + [_c_void_p],
     "dfine_linear_wgrad": [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p],
     "dfine_grad_sumsq": [_c_void_p, ctypes.c_longlong, _c_void_p, _c_void_p],
     "dfine_adamw_ema_step": [_c_void_p] * 8 + [ctypes.POINTER(ctypes.c_longlong), _c_int, ctypes.c_longlong, _c_void_p],
-    "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_void_p],
+    "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
 ABI_VERSION = 1

@@ -359,16 +359,18 @@ static NaGeom make_geom(int n_pix, int C, int ppt, int act, bool has_add, bool h
 template <typename T, int VEC>
 static int fwd_impl(const void* x, const void* addend, void* y, double* sums, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float* save_mean, float* save_rstd, const float* lab_scale,
-                    const float* lab_bias, int n_pix, int C, int act, int training, float eps, float momentum, hipStream_t st) {
+                    const float* lab_bias, int n_pix, int C, int act, int training, float eps, float momentum, int phase,
+                    hipStream_t st) {
   NaLaunch R, A;
   if (int rc = plan<VEC>(&R, n_pix, C, 512)) return rc;   // reductions: few blocks -> few contended atomics
   if (int rc = plan<VEC>(&A, n_pix, C, 1024)) return rc;  // streaming: ~4 blocks per CU, several pixels per thread
-  if (training) {
+  if (training && phase != 2) {
     NaGeom g = make_geom(n_pix, C, R.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, momentum);
     const size_t lds = (size_t)R.block.y * 2 * R.block.x * VEC * sizeof(float);
     hipLaunchKernelGGL((bn_stats_kernel<T, VEC>), R.grid, R.block, lds, st, (const T*)x, sums, g);
     DFINE_LAUNCH_CHECK();
   }
+  if (phase == 1) return 0;
   NaGeom g = make_geom(n_pix, C, A.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, momentum);
   hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), A.grid, A.block, (size_t)2 * A.block.x * VEC * sizeof(float), st, (const T*)x, (const T*)addend, (T*)y, sums, gamma, beta,
                      running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, g);
@@ -380,15 +382,18 @@ template <typename T, int VEC>
 static int bwd_impl(const void* x, const void* addend, const void* dy, const float* save_mean, const float* save_rstd,
                     const float* gamma, const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
                     float* dgamma, float* dbeta, float* dlab_scale, float* dlab_bias, int n_pix, int C, int act, int training,
-                    float eps, hipStream_t st) {
+                    float eps, int phase, hipStream_t st) {
   NaLaunch R, A;
   if (int rc = plan<VEC>(&R, n_pix, C, 512)) return rc;
   if (int rc = plan<VEC>(&A, n_pix, C, 1024)) return rc;
   NaGeom g = make_geom(n_pix, C, R.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, 0.f);
-  const size_t lds = (size_t)R.block.y * 4 * R.block.x * VEC * sizeof(float);
-  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy,
-                     save_mean, save_rstd, gamma, beta, lab_scale, red, g);
-  DFINE_LAUNCH_CHECK();
+  if (phase != 2) {
+    const size_t lds = (size_t)R.block.y * 4 * R.block.x * VEC * sizeof(float);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy,
+                       save_mean, save_rstd, gamma, beta, lab_scale, red, g);
+    DFINE_LAUNCH_CHECK();
+  }
+  if (phase == 1) return 0;
   g.pix_per_thread = A.ppt;
   hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VEC>), A.grid, A.block, (size_t)6 * A.block.x * VEC * sizeof(float), st, (const T*)x, (const T*)addend, (const T*)dy, save_mean,
                      save_rstd, gamma, beta, lab_scale, red, (T*)dx, (T*)dadd, dgamma, dbeta, dlab_scale, dlab_bias, g);
@@ -421,13 +426,13 @@ extern "C" int dfine_bn_act_fwd(const void* x, const void* addend, void* y, int 
                                 const float* gamma, const float* beta, float* running_mean,
                                 float* running_var, float* save_mean, float* save_rstd,
                                 const float* lab_scale, const float* lab_bias, int n_pix, int C, int act, int training, float eps,
-                                float momentum, void* stream) {
+                                float momentum, int phase, void* stream) {
   if (!x || !y || !gamma || !beta || !running_mean || !running_var) return DFINE_E_BADARG;
   if (training && (!sums || !save_mean || !save_rstd)) return DFINE_E_BADARG;
-  if (n_pix <= 0 || C <= 0 || act < 0 || act > 2) return DFINE_E_BADARG;
+  if (n_pix <= 0 || C <= 0 || act < 0 || act > 2 || phase < 0 || phase > 2) return DFINE_E_BADARG;
   if ((lab_scale != nullptr) != (lab_bias != nullptr)) return DFINE_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-#define FWD(T, V) fwd_impl<T, V>(x, addend, y, sums, gamma, beta, running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, n_pix, C, act, training, eps, momentum, st)
+#define FWD(T, V) fwd_impl<T, V>(x, addend, y, sums, gamma, beta, running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, n_pix, C, act, training, eps, momentum, phase, st)
   DFINE_NA_DISPATCH(FWD);
 #undef FWD
 }
@@ -436,13 +441,13 @@ extern "C" int dfine_bn_act_bwd(const void* x, const void* addend, const void* d
                                 const float* save_mean, const float* save_rstd, const float* gamma,
                                 const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
                                 float* dgamma, float* dbeta, float* dlab_scale, float* dlab_bias, int n_pix,
-                                int C, int act, int training, float eps, void* stream) {
+                                int C, int act, int training, float eps, int phase, void* stream) {
   if (!x || !dy || !save_mean || !save_rstd || !gamma || !beta || !red || !dx || !dgamma || !dbeta) return DFINE_E_BADARG;
   if ((addend != nullptr) != (dadd != nullptr)) return DFINE_E_BADARG;
   if (lab_scale && (!dlab_scale || !dlab_bias)) return DFINE_E_BADARG;
-  if (n_pix <= 0 || C <= 0 || act < 0 || act > 2) return DFINE_E_BADARG;
+  if (n_pix <= 0 || C <= 0 || act < 0 || act > 2 || phase < 0 || phase > 2) return DFINE_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-#define BWD(T, V) bwd_impl<T, V>(x, addend, dy, save_mean, save_rstd, gamma, beta, lab_scale, red, dx, dadd, dgamma, dbeta, dlab_scale, dlab_bias, n_pix, C, act, training, eps, st)
+#define BWD(T, V) bwd_impl<T, V>(x, addend, dy, save_mean, save_rstd, gamma, beta, lab_scale, red, dx, dadd, dgamma, dbeta, dlab_scale, dlab_bias, n_pix, C, act, training, eps, phase, st)
   DFINE_NA_DISPATCH(BWD);
 #undef BWD
 }

@@ -236,7 +236,7 @@ class _DepthwiseConv2d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             wp = ctx.weight
             direct = (DIRECT_WGRAD_ACCUM and wp.grad is not None and wp.grad.dtype == torch.float32
-                      and wp.grad.stride() == (k * k, k * k, k, 1))  # [C,1,k,k] laid out as C*k*k (channels_last with 1 channel)
+                      and wp.grad.stride() in ((k * k, k * k, k, 1), (k * k, 1, k, 1)))  # memory order [C][k][k] either way
             dw = wp.grad if direct else torch.zeros(C, 1, k, k, dtype=torch.float32, device=xl.device)
             n_ws = lib.dfine_dwconv_bwd_weight_workspace(B, H, W, C, k, stride)
             if n_ws < 0:
@@ -286,12 +286,16 @@ class _BatchNormAct(torch.autograd.Function):
         g32, b32 = gamma.detach().float(), beta.detach().float()
         ls32 = lab_scale.detach().float() if lab_scale is not None else None
         lb32 = lab_bias.detach().float() if lab_bias is not None else None
-        nbytes = (2 * xl.numel() + y.numel() + (al.numel() if al is not None else 0)) * xl.element_size()
-        with _lib.timed("bn_act_fwd", nbytes):
-            rc = lib.dfine_bn_act_fwd(_lib.ptr(xl), _lib.ptr(al), _lib.ptr(y), _lib.dtype_code(xl), _lib.ptr(sums),
-                                      _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(running_mean), _lib.ptr(running_var),
-                                      _lib.ptr(save_mean), _lib.ptr(save_rstd), _lib.ptr(ls32), _lib.ptr(lb32), n_pix, C,
-                                      _ACT_CODES[act], int(training), eps, momentum, _lib.stream_ptr())
+        es = xl.element_size()
+        args = (_lib.ptr(xl), _lib.ptr(al), _lib.ptr(y), _lib.dtype_code(xl), _lib.ptr(sums), _lib.ptr(g32), _lib.ptr(b32),
+                _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean), _lib.ptr(save_rstd), _lib.ptr(ls32),
+                _lib.ptr(lb32), n_pix, C, _ACT_CODES[act], int(training), eps, momentum)
+        rc = 0
+        if training:
+            with _lib.timed("bn_stats", xl.numel() * es):
+                rc = lib.dfine_bn_act_fwd(*args, 1, _lib.stream_ptr())
+        with _lib.timed("bn_apply", (xl.numel() + y.numel() + (al.numel() if al is not None else 0)) * es):
+            rc = rc or lib.dfine_bn_act_fwd(*args, 2, _lib.stream_ptr())
         _lib.check(rc, "dfine_bn_act_fwd")
         ctx.save_for_backward(xl, al, g32, b32, save_mean, save_rstd, ls32)
         ctx.cfg = (act, eps, int(training), gamma.dtype, lab_scale.dtype if lab_scale is not None else None)
@@ -321,14 +325,16 @@ class _BatchNormAct(torch.autograd.Function):
             dgamma, dbeta = gamma_p.grad, beta_p.grad
             if ls32 is not None:
                 dls, dlb = ls_p.grad, lb_p.grad
-        nbytes = (2 * xl.numel() + 3 * gy.numel() + (2 * al.numel() if al is not None else 0)) * xl.element_size()
-        with _lib.timed("bn_act_bwd", nbytes):
-            rc = lib.dfine_bn_act_bwd(_lib.ptr(xl), _lib.ptr(al), _lib.ptr(gy), _lib.dtype_code(xl), _lib.ptr(save_mean),
-                                      _lib.ptr(save_rstd), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(ls32), _lib.ptr(red),
-                                      _lib.ptr(dx), _lib.ptr(dadd), _lib.ptr(dgamma), _lib.ptr(dbeta),
-                                      _lib.ptr(dls) if ls32 is not None else None,
-                                      _lib.ptr(dlb) if ls32 is not None else None, n_pix, C, _ACT_CODES[act],
-                                      training, eps, _lib.stream_ptr())
+        es = xl.element_size()
+        n_add = al.numel() if al is not None else 0
+        args = (_lib.ptr(xl), _lib.ptr(al), _lib.ptr(gy), _lib.dtype_code(xl), _lib.ptr(save_mean), _lib.ptr(save_rstd),
+                _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(ls32), _lib.ptr(red), _lib.ptr(dx), _lib.ptr(dadd), _lib.ptr(dgamma),
+                _lib.ptr(dbeta), _lib.ptr(dls) if ls32 is not None else None, _lib.ptr(dlb) if ls32 is not None else None,
+                n_pix, C, _ACT_CODES[act], training, eps)
+        with _lib.timed("bn_bwd_reduce", (xl.numel() + gy.numel() + n_add) * es):
+            rc = lib.dfine_bn_act_bwd(*args, 1, _lib.stream_ptr())
+        with _lib.timed("bn_bwd_dx", (xl.numel() + 2 * gy.numel() + 2 * n_add) * es):
+            rc = rc or lib.dfine_bn_act_bwd(*args, 2, _lib.stream_ptr())
         _lib.check(rc, "dfine_bn_act_bwd")
         if direct:
             return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None) + (None,) * 10

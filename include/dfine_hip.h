@@ -147,17 +147,20 @@ int dfine_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* wor
  *   sums f64 [2*C], red f64 [4*C]: workspaces, ZEROED by the caller before the call
  *   act: 0 identity, 1 ReLU, 2 SiLU.  training=1: batch statistics, running stats updated
  *   (momentum, unbiased variance); training=0 (forward only): running statistics.
+ *   phase: each direction is two kernels (forward: statistics, apply; backward: reductions, dx).
+ *       0 = launch both, 1 = only the first, 2 = only the second (so a caller can time them apart).
  * Any C (the widest channel vector <= 16 bytes that divides C is used).
  * ------------------------------------------------------------------------------------- */
 int dfine_bn_act_fwd(const void* x, const void* addend, void* y, int dtype, double* sums,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float* save_mean, float* save_rstd, const float* lab_scale, const float* lab_bias,
-                     int n_pix, int C, int act, int training, float eps, float momentum, void* stream);
+                     int n_pix, int C, int act, int training, float eps, float momentum, int phase,
+                     void* stream);
 int dfine_bn_act_bwd(const void* x, const void* addend, const void* dy, int dtype,
                      const float* save_mean, const float* save_rstd, const float* gamma,
                      const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
                      float* dgamma, float* dbeta, float* dlab_scale, float* dlab_bias, int n_pix, int C,
-                     int act, int training, float eps, void* stream);
+                     int act, int training, float eps, int phase, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Optimizer tail over FLAT fp32 buffers of n elements (all trainable parameters, grouped).
