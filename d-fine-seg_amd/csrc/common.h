@@ -88,6 +88,21 @@ __device__ __forceinline__ void load_vec(const T* p, float* f) {
   for (int i = 0; i < VEC; ++i) f[i] = VecTraits<T>::load1(&u.e[i]);
 }
 
+// the same access split in two: keep the packed bytes in registers (1/2 the VGPRs of fp32 for bf16)
+// while several loads are in flight, convert when the values are used
+template <typename T, int VEC>
+struct PackedVec {
+  typedef typename RawBytes<VEC * sizeof(T)>::type raw_t;
+  raw_t raw;
+  __device__ __forceinline__ void load(const T* p) { raw = *reinterpret_cast<const raw_t*>(p); }
+  __device__ __forceinline__ void unpack(float* f) const {
+    union { raw_t r; T e[VEC]; } u;
+    u.r = raw;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] = VecTraits<T>::load1(&u.e[i]);
+  }
+};
+
 __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void store1(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 

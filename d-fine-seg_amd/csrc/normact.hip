@@ -13,11 +13,17 @@
 // x / addend / y / dy / dx / dadd: [n_pix, C] (= [B, H, W, C]) of T (bf16 or f32). Statistics are
 // accumulated as fp32 partials per thread and combined with fp64 atomics (the conv outputs of this
 // model can have |mean| >> std; fp64 keeps E[x^2] - E[x]^2 exact enough).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dfine {
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+
+// The per-channel sums are accumulated in NA_REPLICAS copies (block b adds into copy b % NA_REPLICAS)
+// and summed by the consumer: thousands of blocks adding into one set of C addresses serialise.
+constexpr int NA_REPLICAS = 8;
 
 struct NaGeom {
   int n_pix, C;
@@ -60,7 +66,7 @@ struct ColReduce {
       float s = 0.f;
       for (int r = 0; r < (int)blockDim.y; ++r) s += red[(size_t)r * NQ * lanes + e];
       const int q = e / lanes, c = e - q * lanes;
-      atomicAdd(out + (size_t)q * C + (c0 - threadIdx.x * VEC) + c, (double)s);
+      atomicAdd(out + ((size_t)(blockIdx.x % NA_REPLICAS) * NQ + q) * C + (c0 - threadIdx.x * VEC) + c, (double)s);
     }
   }
 };
@@ -69,6 +75,7 @@ struct ColReduce {
 // (the maps are 6-100 MB: at that size a kernel is latency-bound unless each wave keeps several
 // 16-byte loads in flight), and fetches its per-channel constants once per block through LDS.
 #define DFINE_NA_UNROLL 4
+#define DFINE_NA_UNROLL_BWD 2  // x, dy (+addend) per pixel: 2 pixels already keep 4-6 loads in flight
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, double* __restrict__ sums, NaGeom g) {
@@ -117,8 +124,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     const int c = cbase + k;
     float mean, rstd;
     if (g.training) {
-      const double m = sums[c] / g.n_pix;
-      double v = sums[g.C + c] / g.n_pix - m * m;
+      double s1 = 0, s2 = 0;
+#pragma unroll
+      for (int rep = 0; rep < NA_REPLICAS; ++rep) {
+        s1 += sums[(size_t)rep * 2 * g.C + c];
+        s2 += sums[(size_t)rep * 2 * g.C + g.C + c];
+      }
+      const double m = s1 / g.n_pix;
+      double v = s2 / g.n_pix - m * m;
       if (v < 0) v = 0;
       mean = (float)m;
       const float var = (float)v;
@@ -212,33 +225,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[q][i] = 0.f;
   const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
-  for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL) {
-    float v[DFINE_NA_UNROLL][VEC], a[DFINE_NA_UNROLL][VEC], d[DFINE_NA_UNROLL][VEC];
-    bool ok[DFINE_NA_UNROLL];
+  for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL_BWD) {
+    PackedVec<T, VEC> px[DFINE_NA_UNROLL_BWD], pa[DFINE_NA_UNROLL_BWD], pd[DFINE_NA_UNROLL_BWD];
+    bool ok[DFINE_NA_UNROLL_BWD];
 #pragma unroll
-    for (int u = 0; u < DFINE_NA_UNROLL; ++u) {
+    for (int u = 0; u < DFINE_NA_UNROLL_BWD; ++u) {
       const int pix = first + (n + u) * blockDim.y;
       ok[u] = n + u < g.pix_per_thread && pix < g.n_pix;
       if (ok[u]) {
         const size_t off = (size_t)pix * g.C + c0;
-        load_vec<T, VEC>(x + off, v[u]);
-        load_vec<T, VEC>(dy + off, d[u]);
-        if (g.has_add) load_vec<T, VEC>(addend + off, a[u]);
+        px[u].load(x + off);
+        pd[u].load(dy + off);
+        if (g.has_add) pa[u].load(addend + off);
       }
     }
 #pragma unroll
-    for (int u = 0; u < DFINE_NA_UNROLL; ++u) {
+    for (int u = 0; u < DFINE_NA_UNROLL_BWD; ++u) {
       if (!ok[u]) continue;
+      float v[VEC], a[VEC], d[VEC];
+      px[u].unpack(v);
+      pd[u].unpack(d);
+      if (g.has_add) pa[u].unpack(a);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        const float xhat = (v[u][i] - mean[i]) * rstd[i];
+        const float xhat = (v[i] - mean[i]) * rstd[i];
         float z = xhat * gam[i] + bet[i];
-        if (g.has_add) z += a[u][i];
-        const float dz = d[u][i] * ls * act_grad(z, g.act);
+        if (g.has_add) z += a[i];
+        const float dz = d[i] * ls * act_grad(z, g.act);
         acc[0][i] += dz;
         acc[1][i] += dz * xhat;
-        acc[2][i] += d[u][i] * act_fwd(z, g.act);
-        acc[3][i] += d[u][i];
+        acc[2][i] += d[i] * act_fwd(z, g.act);
+        acc[3][i] += d[i];
       }
     }
   }
@@ -262,7 +279,13 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
   const float inv_n = 1.f / (float)g.n_pix;
   for (int k = tid; k < lanes; k += blockDim.x * blockDim.y) {
     const int c = cbase + k;
-    const float s_dz = (float)red_in[c], s_dzx = (float)red_in[g.C + c];
+    double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+#pragma unroll
+    for (int rep = 0; rep < NA_REPLICAS; ++rep) {
+      const double* rr = red_in + (size_t)rep * 4 * g.C;
+      r0 += rr[c]; r1 += rr[g.C + c]; r2 += rr[2 * g.C + c]; r3 += rr[3 * g.C + c];
+    }
+    const float s_dz = (float)r0, s_dzx = (float)r1;
     cst[k] = save_mean[c];
     cst[lanes + k] = save_rstd[c];
     cst[2 * lanes + k] = gamma[c];
@@ -273,8 +296,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
       dgamma[c] += s_dzx;
       dbeta[c] += s_dz;
       if (g.has_lab) {
-        atomicAdd(dlab_scale, (float)red_in[2 * g.C + c]);
-        atomicAdd(dlab_bias, (float)red_in[3 * g.C + c]);
+        atomicAdd(dlab_scale, (float)r2);
+        atomicAdd(dlab_bias, (float)r3);
       }
     }
   }
@@ -293,37 +316,51 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
   }
   const float ls = g.has_lab ? lab_scale[0] : 1.f;
   const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
-  for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL) {
-    float v[DFINE_NA_UNROLL][VEC], a[DFINE_NA_UNROLL][VEC], d[DFINE_NA_UNROLL][VEC];
-    bool ok[DFINE_NA_UNROLL];
+  for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL_BWD) {
+    PackedVec<T, VEC> px[DFINE_NA_UNROLL_BWD], pa[DFINE_NA_UNROLL_BWD], pd[DFINE_NA_UNROLL_BWD];
+    bool ok[DFINE_NA_UNROLL_BWD];
 #pragma unroll
-    for (int u = 0; u < DFINE_NA_UNROLL; ++u) {
+    for (int u = 0; u < DFINE_NA_UNROLL_BWD; ++u) {
       const int pix = first + (n + u) * blockDim.y;
       ok[u] = n + u < g.pix_per_thread && pix < g.n_pix;
       if (ok[u]) {
         const size_t off = (size_t)pix * g.C + c0;
-        load_vec<T, VEC>(x + off, v[u]);
-        load_vec<T, VEC>(dy + off, d[u]);
-        if (g.has_add) load_vec<T, VEC>(addend + off, a[u]);
+        px[u].load(x + off);
+        pd[u].load(dy + off);
+        if (g.has_add) pa[u].load(addend + off);
       }
     }
 #pragma unroll
-    for (int u = 0; u < DFINE_NA_UNROLL; ++u) {
+    for (int u = 0; u < DFINE_NA_UNROLL_BWD; ++u) {
       if (!ok[u]) continue;
       const size_t off = (size_t)(first + (n + u) * blockDim.y) * g.C + c0;
+      float v[VEC], a[VEC], d[VEC];
+      px[u].unpack(v);
+      pd[u].unpack(d);
+      if (g.has_add) pa[u].unpack(a);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        const float xhat = (v[u][i] - mean[i]) * rstd[i];
+        const float xhat = (v[i] - mean[i]) * rstd[i];
         float z = xhat * gam[i] + bet[i];
-        if (g.has_add) z += a[u][i];
-        const float dz = d[u][i] * ls * act_grad(z, g.act);
-        a[u][i] = dz;
-        v[u][i] = gam[i] * rstd[i] * (dz - m_dz[i] - xhat * m_dzx[i]);
+        if (g.has_add) z += a[i];
+        const float dz = d[i] * ls * act_grad(z, g.act);
+        a[i] = dz;
+        v[i] = gam[i] * rstd[i] * (dz - m_dz[i] - xhat * m_dzx[i]);
       }
-      store_vec<T, VEC>(dx + off, v[u]);
-      if (g.has_add) store_vec<T, VEC>(dadd + off, a[u]);
+      store_vec<T, VEC>(dx + off, v);
+      if (g.has_add) store_vec<T, VEC>(dadd + off, a);
     }
   }
+}
+
+static int reduce_target_blocks() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DFINE_BN_REDUCE_BLOCKS");
+    v = e ? atoi(e) : 512;
+    if (v < 64) v = 64;
+  }
+  return v;
 }
 
 struct NaLaunch {
@@ -362,7 +399,7 @@ static int fwd_impl(const void* x, const void* addend, void* y, double* sums, co
                     const float* lab_bias, int n_pix, int C, int act, int training, float eps, float momentum, int phase,
                     hipStream_t st) {
   NaLaunch R, A;
-  if (int rc = plan<VEC>(&R, n_pix, C, 512)) return rc;   // reductions: few blocks -> few contended atomics
+  if (int rc = plan<VEC>(&R, n_pix, C, reduce_target_blocks())) return rc;   // reductions: few blocks -> few contended atomics
   if (int rc = plan<VEC>(&A, n_pix, C, 1024)) return rc;  // streaming: ~4 blocks per CU, several pixels per thread
   if (training && phase != 2) {
     NaGeom g = make_geom(n_pix, C, R.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, momentum);
@@ -384,7 +421,7 @@ static int bwd_impl(const void* x, const void* addend, const void* dy, const flo
                     float* dgamma, float* dbeta, float* dlab_scale, float* dlab_bias, int n_pix, int C, int act, int training,
                     float eps, int phase, hipStream_t st) {
   NaLaunch R, A;
-  if (int rc = plan<VEC>(&R, n_pix, C, 512)) return rc;
+  if (int rc = plan<VEC>(&R, n_pix, C, reduce_target_blocks())) return rc;
   if (int rc = plan<VEC>(&A, n_pix, C, 1024)) return rc;
   NaGeom g = make_geom(n_pix, C, R.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, 0.f);
   if (phase != 2) {

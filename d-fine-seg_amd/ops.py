@@ -280,9 +280,9 @@ class _BatchNormAct(torch.autograd.Function):
         al = _nhwc(addend.to(x.dtype)) if addend is not None else None
         n_pix = B * H * W
         y = torch.empty_like(xl)
-        # one zeroed workspace: fp64 sums [2C] (as 4C floats) | save_mean [C] | save_rstd [C]
-        ws = zeros_f32(6 * C, x.device)
-        sums, save_mean, save_rstd = ws[: 4 * C], ws[4 * C : 5 * C], ws[5 * C :]
+        # one zeroed workspace: fp64 sums [8 replicas][2C] (as 32C floats) | save_mean [C] | save_rstd [C]
+        ws = zeros_f32(34 * C, x.device)
+        sums, save_mean, save_rstd = ws[: 32 * C], ws[32 * C : 33 * C], ws[33 * C :]
         g32, b32 = gamma.detach().float(), beta.detach().float()
         ls32 = lab_scale.detach().float() if lab_scale is not None else None
         lb32 = lab_bias.detach().float() if lab_bias is not None else None
@@ -313,9 +313,9 @@ class _BatchNormAct(torch.autograd.Function):
         gy = _nhwc(grad_y.to(xl.dtype))
         dx = torch.empty_like(xl)
         dadd = torch.empty_like(xl) if al is not None else None
-        # one zeroed workspace: fp64 reductions [4C] (as 8C floats) | dgamma [C] | dbeta [C] | dlab [2]
-        ws = zeros_f32(10 * C + 2, xl.device)
-        red, dgamma, dbeta, dlab = ws[: 8 * C], ws[8 * C : 9 * C], ws[9 * C : 10 * C], ws[10 * C :]
+        # one zeroed workspace: fp64 reductions [8 replicas][4C] (as 64C floats) | dgamma [C] | dbeta [C] | dlab [2]
+        ws = zeros_f32(66 * C + 2, xl.device)
+        red, dgamma, dbeta, dlab = ws[: 64 * C], ws[64 * C : 65 * C], ws[65 * C : 66 * C], ws[66 * C :]
         gamma_p, beta_p, ls_p, lb_p = ctx.params
         plist = [gamma_p, beta_p] + ([ls_p, lb_p] if ls32 is not None else [])
         direct = DIRECT_WGRAD_ACCUM and all(

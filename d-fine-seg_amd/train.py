@@ -95,7 +95,7 @@ class TrainStep:
         if self.device.type == "cuda":  # zero-initialised scratch for the fused ops: one memset per step
             from . import ops
 
-            ops.zero_arena = ops.ZeroArena(4 << 20, self.device)
+            ops.zero_arena = ops.ZeroArena(16 << 20, self.device)
         self.model.train()
 
     # ------------------------------------------------------------------ one step, device side

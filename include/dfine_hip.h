@@ -144,7 +144,8 @@ int dfine_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* wor
  *   dgamma, dbeta f32 [C]: ACCUMULATED (+=; zeroed scratch or the parameters' fp32 .grad)
  *   lab_scale, lab_bias  f32 [1] each on the device (both or neither);  dlab_scale, dlab_bias f32 [1]
  *       each, ACCUMULATED (zeroed scratch or the parameters' fp32 .grad)
- *   sums f64 [2*C], red f64 [4*C]: workspaces, ZEROED by the caller before the call
+ *   sums f64 [8][2*C], red f64 [8][4*C]: workspaces (8 replicas against atomic contention), ZEROED by
+ *       the caller before the call
  *   act: 0 identity, 1 ReLU, 2 SiLU.  training=1: batch statistics, running stats updated
  *   (momentum, unbiased variance); training=0 (forward only): running statistics.
  *   phase: each direction is two kernels (forward: statistics, apply; backward: reductions, dx).
