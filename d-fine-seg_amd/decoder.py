@@ -74,7 +74,7 @@ class MSDeformableAttention(nn.Module):
         nn.init.zeros_(self.attention_weights.weight)
         nn.init.zeros_(self.attention_weights.bias)
 
-    def forward(self, query, ref_boxes, value, spatial_shapes):
+    def forward(self, query, ref_boxes, value, spatial_shapes, sink=None, finalize=True):
         """query [B,Lq,D]; ref_boxes [B,Lq,4] cxcywh; value [B,S,nH,c] channel-last memory."""
         B, Lq, _ = query.shape
         nH, P = self.n_head, sum(self.num_points)
@@ -82,7 +82,7 @@ class MSDeformableAttention(nn.Module):
         weights = torch.softmax(self.attention_weights(query).float().view(B, Lq, nH, P), dim=-1)
         ref = ref_boxes.float()[:, :, None, None, :]
         loc = ref[..., :2] + offsets * (self.num_points_scale.view(P, 1) * 0.5) * ref[..., 2:]
-        return ops.deformable_attention_core(value, spatial_shapes, loc, weights, self.num_points)
+        return ops.deformable_attention_core(value, spatial_shapes, loc, weights, self.num_points, sink, finalize)
 
 
 class Gate(nn.Module):
@@ -111,9 +111,9 @@ class DecoderLayer(nn.Module):
         nn.init.xavier_uniform_(self.linear1.weight)
         nn.init.xavier_uniform_(self.linear2.weight)
 
-    def forward(self, tgt, ref_boxes, value, spatial_shapes, blocked, pos):
+    def forward(self, tgt, ref_boxes, value, spatial_shapes, blocked, pos, sink=None, finalize=True):
         tgt = self.norm1(tgt + self.self_attn(tgt + pos, tgt, blocked))
-        cross = self.cross_attn(tgt + pos, ref_boxes, value, spatial_shapes).to(tgt.dtype)
+        cross = self.cross_attn(tgt + pos, ref_boxes, value, spatial_shapes, sink, finalize).to(tgt.dtype)
         tgt = self.gateway(tgt, cross)
         ffn = self.linear2(F.relu(self.linear1(tgt)))
         return self.norm3((tgt + ffn).clamp(-65504, 65504))
@@ -329,9 +329,10 @@ class DFINETransformer(nn.Module):
         out, out_detach, corners_prev = content, 0, 0
         ref_detach = torch.sigmoid(ref_unact)
         boxes_l, logits_l, corners_l, hs = [], [], [], []
+        sink = ops.ValueGradSink() if (training and torch.is_grad_enabled()) else None
         for i, layer in enumerate(self.decoder.layers):
             pos = self.query_pos_head(ref_detach).clamp(-10, 10)
-            out = layer(out, ref_detach, value, spatial_shapes, blocked, pos)
+            out = layer(out, ref_detach, value, spatial_shapes, blocked, pos, sink, finalize=(i == 0))
             hs.append(out)
             if i == 0:
                 pre_boxes = torch.sigmoid(self.pre_bbox_head(out).float() + inverse_sigmoid(ref_detach))

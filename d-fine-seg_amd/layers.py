@@ -73,6 +73,8 @@ class ConvNorm(nn.Module):
         conv = self.conv
         if conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1:
             x = ops.depthwise_conv2d(x, conv.weight, conv.stride[0])  # HIP: MIOpen has no fast path here
+        elif conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1:
+            x = ops.pointwise_conv(x, conv.weight)  # library fwd/dgrad, HIP wgrad straight into the fp32 grads
         else:
             x = conv(x)
         act_name = act if act is not None else self.act_name

@@ -62,7 +62,8 @@ class _MSDeformAttnCore(torch.autograd.Function):
     """Gather behind decoder cross-attention; see include/dfine_hip.h (dfine_msda_fwd/bwd)."""
 
     @staticmethod
-    def forward(ctx, value, loc, attn, level_hw, num_points):
+    def forward(ctx, value, loc, attn, level_hw, num_points, sink=None, finalize=True):
+        ctx.sink, ctx.finalize = sink, finalize
         _lib.require_gpu(value, loc, attn)
         lib = _lib.load()
         B, S, nH, c = value.shape
@@ -97,7 +98,13 @@ class _MSDeformAttnCore(torch.autograd.Function):
         B, S, nH, c = value.shape
         Lq = loc.shape[1]
         grad_out = grad_out.to(value.dtype).contiguous()
-        grad_value = torch.zeros(B, S, nH, c, dtype=torch.float32, device=value.device)
+        sink = ctx.sink
+        if sink is not None and sink.buffer is not None:
+            grad_value = sink.buffer  # keep accumulating: every decoder layer samples the same value
+        else:
+            grad_value = torch.zeros(B, S, nH, c, dtype=torch.float32, device=value.device)
+            if sink is not None:
+                sink.buffer = grad_value
         grad_loc = torch.empty_like(loc)
         grad_attn = torch.empty_like(attn)
         hw = _lib.i32_array(v for pair in level_hw for v in pair)
@@ -109,7 +116,21 @@ class _MSDeformAttnCore(torch.autograd.Function):
                 B, S, Lq, nH, c, len(num_points), hw, npts, _lib.stream_ptr(),
             )
         _lib.check(rc, "dfine_msda_bwd")
-        return grad_value.to(value.dtype), grad_loc, grad_attn, None, None
+        if sink is not None:
+            if not ctx.finalize:
+                return None, grad_loc, grad_attn, None, None, None, None
+            sink.buffer = None
+        return grad_value.to(value.dtype), grad_loc, grad_attn, None, None, None, None
+
+
+class ValueGradSink:
+    """Shared fp32 accumulator for d(loss)/d(value) when several deformable-attention calls sample the
+    SAME value tensor (all decoder layers do, dfine_decoder.py:449): every call's backward adds its
+    float atomics into one buffer; the call made FIRST in the forward pass (``finalize=True``: its
+    backward runs last) converts it once and hands it to autograd, the others return no value gradient."""
+
+    def __init__(self):
+        self.buffer = None
 
 
 def deformable_attention_core(
@@ -118,6 +139,8 @@ def deformable_attention_core(
     sampling_locations: torch.Tensor,
     attention_weights: torch.Tensor,
     num_points_list: List[int],
+    sink: "ValueGradSink" = None,
+    finalize: bool = True,
 ) -> torch.Tensor:
     """MI355X replacement for ``deformable_attention_core_func_v2(..., method="default")``
     (reference src/d_fine/arch/utils.py:191-264).
@@ -132,6 +155,7 @@ def deformable_attention_core(
     return _MSDeformAttnCore.apply(
         value, sampling_locations, attention_weights,
         [tuple(int(v) for v in hw) for hw in value_spatial_shapes], [int(n) for n in num_points_list],
+        sink, finalize,
     )
 
 
@@ -492,3 +516,50 @@ def linear(x, weight, bias=None, row_begin=0, row_end=None):
         b = bias if (bias is None or (row_begin == 0 and row_end == weight.shape[0])) else bias[row_begin:row_end]
         return torch.nn.functional.linear(x, w, b)
     return _Linear.apply(x, weight, bias, row_begin, row_end)
+
+
+class _PointwiseConv(torch.autograd.Function):
+    """1x1 stride-1 convolution on a channels_last map: forward and input gradient by the library
+    (MIOpen), weight gradient by the split-M MFMA kernel (a 1x1 conv's dW is exactly a Linear's:
+    dW[k][c] = sum over pixels of dY[pix][k] * X[pix][c]) accumulated straight into the fp32 .grad."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        w16 = weight.to(torch.bfloat16)
+        x16 = x.to(torch.bfloat16)
+        y = torch.nn.functional.conv2d(x16, w16)
+        ctx.save_for_backward(x16, w16)
+        ctx.weight = weight
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x16, w16 = ctx.saved_tensors
+        weight = ctx.weight
+        lib = _lib.load()
+        K_out, C_in = w16.shape[0], w16.shape[1]
+        gy16 = gy.to(torch.bfloat16)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(gy16, x16, w16, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
+                                                     (True, False, False))[0]
+        gyl, xl = _nhwc(gy16), _nhwc(x16)  # [B,H,W,K], [B,H,W,C]: row-major [pixels, channels]
+        M = xl.numel() // C_in
+        direct = (DIRECT_WGRAD_ACCUM and weight.grad is not None and weight.grad.dtype == torch.float32
+                  and weight.grad.stride()[:2] == (C_in, 1))
+        dw = weight.grad if direct else torch.zeros(K_out, C_in, 1, 1, dtype=torch.float32, device=xl.device)
+        with _lib.timed("conv1x1_wgrad", (M * K_out + M * C_in) * 2 + K_out * C_in * 4):
+            rc = lib.dfine_linear_wgrad(_lib.ptr(gyl), _lib.ptr(xl), _lib.ptr(dw), None, M, K_out, C_in, C_in, _lib.stream_ptr())
+        _lib.check(rc, "dfine_linear_wgrad")
+        return dx, (None if direct else dw.to(weight.dtype))
+
+
+def pointwise_conv(x, weight):
+    """``F.conv2d(x, weight)`` for a 1x1 stride-1 conv without bias on a channels_last map. In bf16
+    training mode the weight gradient comes from the HIP split-M kernel (no MIOpen fp32 workspace,
+    cast and accumulate launches); otherwise this is plain ``F.conv2d``."""
+    k_out, c_in = weight.shape[0], weight.shape[1]
+    bf16_mode = x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16)
+    if not bf16_mode or k_out % 8 or c_in % 8 or not (weight.requires_grad and torch.is_grad_enabled()):
+        return torch.nn.functional.conv2d(x, weight)
+    return _PointwiseConv.apply(x, weight)

@@ -64,3 +64,26 @@ def test_ops_linear_matches_torch_autograd(hip_lib):
         torch.testing.assert_close(wd.grad, wr.grad, rtol=1e-3, atol=2e-3)
         torch.testing.assert_close(bd.grad, br.grad, rtol=1e-3, atol=2e-3)
         assert float(wd.grad[512:].abs().max()) == 0.0
+
+
+def test_pointwise_conv_matches_torch(hip_lib):
+    """1x1 conv through ops.pointwise_conv (bf16 mode) vs F.conv2d autograd in fp32 on the same values."""
+    import torch.nn.functional as F
+
+    from dfine_seg_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn(2, 96, 20, 24, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = torch.randn(48, 96, 1, 1, device="cuda", generator=g) * 0.1
+    gy = torch.randn(2, 48, 20, 24, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    xr, wr = x.float().requires_grad_(True), w.bfloat16().float().requires_grad_(True)
+    F.conv2d(xr, wr).backward(gy.float())
+    for direct in (True, False):
+        xd, wd = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        if direct:
+            wd.grad = torch.zeros_like(wd)
+        y = ops.pointwise_conv(xd, wd)
+        y.backward(gy)
+        torch.testing.assert_close(y.float(), F.conv2d(xr, wr).detach(), rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(xd.grad.float(), xr.grad, rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(wd.grad, wr.grad, rtol=1e-3, atol=3e-3)
