@@ -44,8 +44,10 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const bf16_t* __restr
                                                            float* __restrict__ dW, float* __restrict__ db,
                                                            int M, int N, int K, int ldw, int m_chunk,
                                                            int k_tiles) {
-  __shared__ __attribute__((aligned(16))) bf16_t a_tile[WG_MSTEP * WG_TILE];  // dY rows m, cols n
-  __shared__ __attribute__((aligned(16))) bf16_t b_tile[WG_MSTEP * WG_TILE];  // X  rows m, cols k
+  // two LDS stages: while the MFMAs consume stage `cur`, the next 32 rows are already in flight from
+  // global memory and are written to the other stage -- one barrier per 32-row step
+  __shared__ __attribute__((aligned(16))) bf16_t a_tile[2][WG_MSTEP * WG_TILE];  // dY rows m, cols n
+  __shared__ __attribute__((aligned(16))) bf16_t b_tile[2][WG_MSTEP * WG_TILE];  // X  rows m, cols k
   __shared__ float bias_red[WG_MSTEP][WG_TILE + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = (blockIdx.x / k_tiles) * WG_TILE, k0 = (blockIdx.x % k_tiles) * WG_TILE;
@@ -61,31 +63,43 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const bf16_t* __restr
 #pragma unroll
   for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
 
-  for (int m0 = m_begin; m0 < m_end; m0 += WG_MSTEP) {
+  auto fetch = [&](int m0, Vec16& va, Vec16& vb) {
     const int m = m0 + r;
-    Vec16 va, vb;
     va.w[0] = va.w[1] = va.w[2] = va.w[3] = 0u;
     vb = va;
     if (m < m_end) {
       if (a_cols) va = *reinterpret_cast<const Vec16*>(dY + (size_t)m * N + n0 + c8);
       if (b_cols) vb = *reinterpret_cast<const Vec16*>(X + (size_t)m * K + k0 + c8);
     }
+  };
+  auto stage = [&](int buf, const Vec16& va, const Vec16& vb) {
     if (want_bias) {
       float f[8];
       VecTraits<bf16_t>::unpack(va, f);
 #pragma unroll
       for (int i = 0; i < 8; ++i) bsum[i] += f[i];
     }
-    __syncthreads();  // everyone is done reading the previous step's tiles
-    *reinterpret_cast<Vec16*>(a_tile + r * WG_TILE + c8) = va;
-    *reinterpret_cast<Vec16*>(b_tile + r * WG_TILE + c8) = vb;
-    __syncthreads();
-    const short8v a = tr_frag(a_tile, 0, 16 * wave, lane);  // this wave's 16 output rows (n)
+    *reinterpret_cast<Vec16*>(a_tile[buf] + r * WG_TILE + c8) = va;
+    *reinterpret_cast<Vec16*>(b_tile[buf] + r * WG_TILE + c8) = vb;
+  };
+
+  Vec16 va, vb;
+  fetch(m_begin, va, vb);
+  stage(0, va, vb);
+  __syncthreads();
+  int cur = 0;
+  for (int m0 = m_begin; m0 < m_end; m0 += WG_MSTEP) {
+    const bool more = m0 + WG_MSTEP < m_end;
+    if (more) fetch(m0 + WG_MSTEP, va, vb);  // global loads overlap the MFMAs below
+    const short8v a = tr_frag(a_tile[cur], 0, 16 * wave, lane);  // this wave's 16 output rows (n)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const short8v b = tr_frag(b_tile, 0, 16 * j, lane);
+      const short8v b = tr_frag(b_tile[cur], 0, 16 * j, lane);
       acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
     }
+    if (more) stage(cur ^ 1, va, vb);  // the other stage was last read one iteration ago (barrier below)
+    __syncthreads();
+    cur ^= 1;
   }
   // C/D layout of mfma_f32_16x16x32: col = lane&15, row = (lane>>4)*4 + reg
   const int col = lane & 15, rbase = (lane >> 4) * 4;
