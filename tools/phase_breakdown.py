@@ -2,7 +2,7 @@
 import collections, csv, sys
 
 def cat(n):
-    if n.startswith('void dfine::'): return 'dfine HIP'
+    if 'dfine::' in n[:16]: return 'dfine HIP (this repo)'
     if 'igemm' in n or 'ck::' in n or '_ZN2ck' in n or 'naive_conv' in n: return 'MIOpen conv'
     if n.startswith('Cijk'): return 'hipBLASLt GEMM'
     if 'SubTensorOp' in n or 'MIOpen' in n: return 'MIOpen misc (tensor ops, BN)'
