@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--task", default="detect", choices=["detect", "segment"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run every step eagerly (no hipGraph capture)")
+    ap.add_argument("--shapes", action="store_true", help="diagnostic: key the per-kernel timings by operand shape")
     return ap.parse_args()
 
 
@@ -131,7 +132,7 @@ def main():
     # steps above replay a captured graph (no Python between kernels to record events from), so the same
     # step is run eagerly a few more times right after the timed region, on the same data and weights.
     probe_steps = 3
-    timer = _lib.KernelTimer()
+    timer = _lib.KernelTimer(by_detail=args.shapes)
     graph_was_on, trainer.use_graph = trainer.use_graph, False
     _lib.set_kernel_timer(timer)
     for _ in range(probe_steps):

@@ -30,6 +30,11 @@ SIGNATURES = {
     "dfine_bn_act_fwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 9 + [_c_int] * 4 + [ctypes.c_float] * 2 + [_c_int, _c_void_p],
     "dfine_criterion_head": [_c_void_p, _c_int] + [_c_void_p] * 17 + [_c_int] * 5 + [ctypes.c_float] * 4 + [_c_void_p],
     "dfine_linear_wgrad": [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p],
+    "dfine_conv_wgrad": [_c_void_p] * 3 + [_c_int] * 11 + [_c_void_p],
+    "dfine_fdr_head_fwd": [_c_void_p] * 6 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, _c_void_p],
+    "dfine_fdr_head_bwd": [_c_void_p] * 7 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, _c_void_p],
+    "dfine_stem_pool_fwd": [_c_void_p, _c_int, _c_void_p] + [_c_int] * 4 + [_c_void_p],
+    "dfine_stem_pool_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p] + [_c_int] * 4 + [_c_void_p],
     "dfine_grad_sumsq": [_c_void_p, ctypes.c_longlong, _c_void_p, _c_void_p],
     "dfine_adamw_ema_step": [_c_void_p] * 8 + [ctypes.POINTER(ctypes.c_longlong), _c_int, ctypes.c_longlong, _c_void_p],
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
@@ -113,8 +118,9 @@ def dtype_code(t):
 class KernelTimer:
     """Collects (start, stop) event pairs per kernel name; ``summary()`` after a device sync."""
 
-    def __init__(self):
+    def __init__(self, by_detail=False):
         self.events = {}
+        self.by_detail = by_detail  # key by "name detail" (e.g. per shape) instead of by name
 
     def summary(self):
         out = {}
@@ -138,8 +144,8 @@ class timed:
     """``with timed("msda_fwd", algorithmic_bytes): launch`` -- a no-op unless a KernelTimer is
     installed. ``nbytes`` is the launch's ALGORITHMIC traffic ("Kernels")."""
 
-    def __init__(self, name, nbytes=0):
-        self.name, self.nbytes = name, nbytes
+    def __init__(self, name, nbytes=0, detail=None):
+        self.name, self.nbytes, self.detail = name, nbytes, detail
 
     def __enter__(self):
         if _timer is not None:
@@ -150,5 +156,6 @@ class timed:
         if _timer is not None:
             stop = torch.cuda.Event(enable_timing=True)
             stop.record(torch.cuda.current_stream())
-            _timer.events.setdefault(self.name, []).append((self.start, stop, self.nbytes))
+            key = f"{self.name} {self.detail}" if (_timer.by_detail and self.detail) else self.name
+            _timer.events.setdefault(key, []).append((self.start, stop, self.nbytes))
         return False

@@ -7,6 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .configs import BACKBONES, ModelSpec
+from . import ops
 from .layers import ConvNorm
 
 
@@ -20,9 +21,13 @@ class Stem(nn.Module):
         self.stem4 = ConvNorm(c_mid, c_out, 1, **kw)
 
     def forward(self, x):
-        x = F.pad(self.stem1(x), (0, 1, 0, 1))  # right/bottom pad so the 2x2 convs keep H, W
+        u = self.stem1(x)
+        x = F.pad(u, (0, 1, 0, 1))  # right/bottom pad so the 2x2 convs keep H, W
         branch = self.stem2b(F.pad(self.stem2a(x), (0, 1, 0, 1)))
-        pooled = F.max_pool2d(x, 2, stride=1, ceil_mode=True)
+        if ops.stem_pool_supported(u):
+            pooled = ops.stem_pool(u)  # HIP: max-pool of the zero-extended map, no padded copy
+        else:
+            pooled = F.max_pool2d(x, 2, stride=1, ceil_mode=True)
         return self.stem4(self.stem3(torch.cat([pooled, branch], 1)))
 
 

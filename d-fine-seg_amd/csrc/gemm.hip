@@ -1,20 +1,31 @@
-// Weight (and bias) gradient of a Linear layer as a split-M MFMA kernel:
-//     dW[n][k] += sum_m dY[m][n] * X[m][k]        db[n] += sum_m dY[m][n]
+// Weight (and bias) gradients as a split-M MFMA kernel:
+//     Linear:  dW[n][k] += sum_m dY[m][n] * X[m][k]        db[n] += sum_m dY[m][n]
+//     Conv:    dW[n][ky][kx][c] += sum_{b,oy,ox} dY[b][oy][ox][n] * X[b][oy*s-p+ky][ox*s-p+kx][c]
 // (autograd of F.linear as used by every MLP / attention projection of the decoder and the AIFI layer,
-// reference src/d_fine/arch/dfine_decoder.py:33-46,181-255 and hybrid_encoder.py:243-290).
+// reference src/d_fine/arch/dfine_decoder.py:33-46,181-255 and hybrid_encoder.py:243-290; autograd of the
+// dense nn.Conv2d inside ConvBNAct / ConvNormLayer, hgnetv2.py:35-80 and hybrid_encoder.py:21-93).
 //
-// Why a kernel of our own: the reduction runs over M = tokens (15 744 for the decoder at batch 32,
-// 268 800 for the encoder memory) while the output is tiny (e.g. 256 x 1024). The stock GEMM
-// (hipBLASLt, no split-K chosen) covers the output with 16-64 tiles of 64x64 and so runs on 16-64 of
-// the 256 CUs: 92-178 us per call, 7.2 ms per step (profiles/). Here the M axis is split across
-// workgroups as well, each accumulating a 64x64 fp32 partial tile with bf16 MFMA and adding it to
-// the fp32 gradient with float atomics -- straight into the flat fp32 gradient buffer, so the bf16
-// grad tensor, its fp32 cast and the accumulate kernel of the stock path disappear too.
+// Why a kernel of our own: the reduction runs over M = tokens or pixels (15 744 decoder tokens at batch
+// 32, 268 800 memory tokens, 819 200 stride-4 pixels) while the output is tiny (e.g. 256 x 1024, or
+// 32 x 288). The stock GEMM (hipBLASLt, no split-K chosen) covers the output with 16-64 tiles and so runs
+// on 16-64 of the 256 CUs; MIOpen's split-K wrw needs a zeroed fp32 workspace, a cast and an accumulate
+// launch around it. Here the M axis is split across workgroups as well, each accumulating an fp32 partial
+// tile with bf16 MFMA and adding it to the fp32 gradient with float atomics -- straight into the flat
+// fp32 gradient buffer.
+//
+// A conv is the same GEMM with K = KH*KW*CI ("im2col" column k = (ky*KW+kx)*CI + c, which IS the memory
+// order of a channels_last weight) whose X rows are gathered: column chunk -> tap is fixed per thread,
+// only the pixel moves.
 //
 // Both operands are row-major with the reduction index m as the SLOW axis, while an MFMA lane wants 8
 // consecutive reduction elements of one output row/column. Tiles are staged row-major in LDS and read
 // back with ds_read_b64_tr_b16 (gfx950's transposing LDS read): a 16-lane group reads a 4(m) x 16(col)
 // block and each lane receives one column's 4 m-values -- two such reads are one MFMA 16x16x32 fragment.
+// Banking of that read is per 32-lane half, i.e. 8 tile rows x 32 bytes at one column offset: with plain
+// 128/256-byte rows those land on 2 (1) bank slots, a 4x (8x) conflict. The 32-byte chunks of a row are
+// therefore XOR-swizzled by row (swz()) so the 8 rows of a half cover the whole 256-byte bank row.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dfine {
@@ -23,128 +34,290 @@ typedef short short4v __attribute__((ext_vector_type(4)));
 typedef short short8v __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
-constexpr int WG_TILE = 64;   // output tile edge (n and k)
 constexpr int WG_MSTEP = 32;  // reduction rows per MFMA step
 
-__device__ __forceinline__ short8v tr_frag(const bf16_t* tile, int row0, int col0, int lane) {
-  // rows row0 + 8*(lane>>4) + {0..7}, column col0 + (lane&15), from a row-major [32][64] tile
+// XOR mask for the 32-byte chunk index of tile row r (TW = tile width in elements)
+template <int TW>
+__device__ __forceinline__ int swz(int r) {
+  if (TW == 128) return (((r >> 3) & 1) << 2) | (r & 3);
+  return (((r >> 3) & 1) << 1) | ((r >> 1) & 1);
+}
+
+// rows 8*(lane>>4) + {0..7}, column col0 + (lane&15) of a swizzled row-major [32][TW] tile; col0 % 16 == 0
+template <int TW>
+__device__ __forceinline__ short8v tr_frag(const bf16_t* tile, int col0, int lane) {
   const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-  const bf16_t* a0 = tile + (row0 + 8 * g + q) * WG_TILE + col0 + 4 * p;
+  const int r = 8 * g + q;
+  const bf16_t* a0 = tile + r * TW + (((col0 >> 4) ^ swz<TW>(r)) << 4) + 4 * p;
   typedef __attribute__((address_space(3))) short4v lds_v4;
   const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)a0);
-  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 4 * WG_TILE));
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 4 * TW));  // swz(r + 4) == swz(r)
   short8v f;
   f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
   f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
   return f;
 }
 
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(const bf16_t* __restrict__ dY,
-                                                           const bf16_t* __restrict__ X,
-                                                           float* __restrict__ dW, float* __restrict__ db,
-                                                           int M, int N, int K, int ldw, int m_chunk,
-                                                           int k_tiles) {
-  // two LDS stages: while the MFMAs consume stage `cur`, the next 32 rows are already in flight from
-  // global memory and are written to the other stage -- one barrier per 32-row step
-  __shared__ __attribute__((aligned(16))) bf16_t a_tile[2][WG_MSTEP * WG_TILE];  // dY rows m, cols n
-  __shared__ __attribute__((aligned(16))) bf16_t b_tile[2][WG_MSTEP * WG_TILE];  // X  rows m, cols k
-  __shared__ float bias_red[WG_MSTEP][WG_TILE + 1];
+struct ConvGeom {
+  int H, W, CI, OH, OW, KW, stride, pad;
+};
+
+// pixel cursor of one staged row: advances by WG_MSTEP output pixels per step without dividing
+struct PixelCursor {
+  int b, oy, ox;
+  __device__ __forceinline__ void init(long long m, const ConvGeom& g) {
+    ox = (int)(m % g.OW);
+    const long long t = m / g.OW;
+    oy = (int)(t % g.OH);
+    b = (int)(t / g.OH);
+  }
+  __device__ __forceinline__ void advance(const ConvGeom& g) {
+    ox += WG_MSTEP;
+    while (ox >= g.OW) {
+      ox -= g.OW;
+      if (++oy == g.OH) { oy = 0; ++b; }
+    }
+  }
+};
+
+template <int TN, int TK, bool CONV, int DEPTH>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
+                                                    float* __restrict__ dW, float* __restrict__ db, int M, int N,
+                                                    int K, int ldw, int m_chunk, int n_chunks, int k_tiles,
+                                                    int tiles, ConvGeom geom) {
+  constexpr int FN = TN / 32, FK = TK / 32;        // 16x16 fragments per wave (waves tile the output 2 x 2)
+  constexpr int A_ROWS = TN / 64, B_ROWS = TK / 64;  // rows each thread stages per step (16-byte chunks)
+  constexpr int A_CPR = TN / 8, B_CPR = TK / 8;    // 16-byte chunks per tile row
+  // ONE LDS array (two stages of both tiles; reused for the bias reduction after the loop)
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * WG_MSTEP * (TN + TK)];
+  bf16_t* const a_tile0 = lds;
+  bf16_t* const b_tile0 = lds + 2 * WG_MSTEP * TN;
+
+  // XCD-aware decode: consecutive workgroup ids go round-robin to the 8 XCDs; all tiles of one m-chunk
+  // share the chunk's dY/X rows, so they are given ids of one residue class (one XCD, one L2)
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int chunk = xcd + 8 * (slot / tiles), tile = slot % tiles;
+  if (chunk >= n_chunks) return;  // whole workgroup, before any barrier
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = (blockIdx.x / k_tiles) * WG_TILE, k0 = (blockIdx.x % k_tiles) * WG_TILE;
-  const int m_begin = blockIdx.y * m_chunk, m_end = min(m_begin + m_chunk, M);
-  const int r = tid >> 3, c8 = (tid & 7) * 8;  // this thread stages row r, 8 columns from c8
-  const bool a_cols = n0 + c8 < N, b_cols = k0 + c8 < K;  // N, K are multiples of 8: a chunk is all in or all out
+  const int wave_n = wave >> 1, wave_k = wave & 1;
+  const int n0 = (tile / k_tiles) * TN, k0 = (tile % k_tiles) * TK;
+  const int m_begin = chunk * m_chunk, m_end = min(m_begin + m_chunk, M);
   const bool want_bias = db != nullptr && k0 == 0;
 
-  float4v acc[4];
+  // staging coordinates: thread -> (row, 16-byte chunk) per operand
+  const int a_r = tid / A_CPR, a_j = tid % A_CPR;  // further rows at +256/A_CPR
+  const int b_r = tid / B_CPR, b_j = tid % B_CPR;
+  constexpr int A_RSTEP = 256 / A_CPR, B_RSTEP = 256 / B_CPR;
+  const bool a_cols = n0 + a_j * 8 < N, b_cols = k0 + b_j * 8 < K;  // N, K multiples of 8: all in or all out
+  int tap_dy = 0, tap_dx = 0, chan = 0;
+  PixelCursor cur_px[B_ROWS];
+  if (CONV) {
+    const int kk = k0 + b_j * 8;
+    const int tap = kk / geom.CI;
+    chan = kk % geom.CI;
+    tap_dy = tap / geom.KW - geom.pad;
+    tap_dx = tap % geom.KW - geom.pad;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = float4v{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < B_ROWS; ++i) cur_px[i].init((long long)m_begin + b_r + i * B_RSTEP, geom);
+  }
+
+  float4v acc[FN][FK];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FK; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
   float bsum[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
 
-  auto fetch = [&](int m0, Vec16& va, Vec16& vb) {
-    const int m = m0 + r;
-    va.w[0] = va.w[1] = va.w[2] = va.w[3] = 0u;
-    vb = va;
-    if (m < m_end) {
-      if (a_cols) va = *reinterpret_cast<const Vec16*>(dY + (size_t)m * N + n0 + c8);
-      if (b_cols) vb = *reinterpret_cast<const Vec16*>(X + (size_t)m * K + k0 + c8);
+  // Register ring of DEPTH future steps: the loads of step s+DEPTH are issued while step s is computed,
+  // so DEPTH * (TN + TK) * 64 bytes per workgroup are in flight -- one step ahead is not enough to cover
+  // the ~2 us a loaded HBM/Infinity-Cache round trip takes (measured: 380 TFLOP/s, time per step = latency).
+  Vec16 va[DEPTH][A_ROWS], vb[DEPTH][B_ROWS];
+  auto fetch = [&](int slot, int m0) {
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+      const int m = m0 + a_r + i * A_RSTEP;
+      va[slot][i].w[0] = va[slot][i].w[1] = va[slot][i].w[2] = va[slot][i].w[3] = 0u;
+      if (m < m_end && a_cols) va[slot][i] = *reinterpret_cast<const Vec16*>(dY + (size_t)m * N + n0 + a_j * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) {
+      const int m = m0 + b_r + i * B_RSTEP;
+      vb[slot][i].w[0] = vb[slot][i].w[1] = vb[slot][i].w[2] = vb[slot][i].w[3] = 0u;
+      if (CONV) {
+        const int iy = cur_px[i].oy * geom.stride + tap_dy, ix = cur_px[i].ox * geom.stride + tap_dx;
+        if (m < m_end && b_cols && (unsigned)iy < (unsigned)geom.H && (unsigned)ix < (unsigned)geom.W)
+          vb[slot][i] = *reinterpret_cast<const Vec16*>(X + (((size_t)cur_px[i].b * geom.H + iy) * geom.W + ix) * geom.CI + chan);
+        cur_px[i].advance(geom);
+      } else {
+        if (m < m_end && b_cols) vb[slot][i] = *reinterpret_cast<const Vec16*>(X + (size_t)m * K + k0 + b_j * 8);
+      }
     }
   };
-  auto stage = [&](int buf, const Vec16& va, const Vec16& vb) {
-    if (want_bias) {
-      float f[8];
-      VecTraits<bf16_t>::unpack(va, f);
+  auto stage = [&](int buf, int slot) {
+    bf16_t* at = a_tile0 + buf * WG_MSTEP * TN;
+    bf16_t* bt = b_tile0 + buf * WG_MSTEP * TK;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) bsum[i] += f[i];
+    for (int i = 0; i < A_ROWS; ++i) {
+      if (want_bias) {
+        float f[8];
+        VecTraits<bf16_t>::unpack(va[slot][i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += f[e];
+      }
+      const int r = a_r + i * A_RSTEP;
+      *reinterpret_cast<Vec16*>(at + r * TN + ((((a_j >> 1) ^ swz<TN>(r)) << 1) | (a_j & 1)) * 8) = va[slot][i];
     }
-    *reinterpret_cast<Vec16*>(a_tile[buf] + r * WG_TILE + c8) = va;
-    *reinterpret_cast<Vec16*>(b_tile[buf] + r * WG_TILE + c8) = vb;
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) {
+      const int r = b_r + i * B_RSTEP;
+      *reinterpret_cast<Vec16*>(bt + r * TK + ((((b_j >> 1) ^ swz<TK>(r)) << 1) | (b_j & 1)) * 8) = vb[slot][i];
+    }
   };
 
-  Vec16 va, vb;
-  fetch(m_begin, va, vb);
-  stage(0, va, vb);
-  __syncthreads();
-  int cur = 0;
-  for (int m0 = m_begin; m0 < m_end; m0 += WG_MSTEP) {
-    const bool more = m0 + WG_MSTEP < m_end;
-    if (more) fetch(m0 + WG_MSTEP, va, vb);  // global loads overlap the MFMAs below
-    const short8v a = tr_frag(a_tile[cur], 0, 16 * wave, lane);  // this wave's 16 output rows (n)
+  // Two LDS stages, one barrier per 32-row step. Ring slot k holds a step == k (mod DEPTH); the loop is
+  // unrolled by DEPTH (even) so slots and LDS stages are compile-time indices. Rows at or beyond m_end are
+  // fetched as zeros, so every workgroup simply runs a multiple of DEPTH steps.
+  const int n_steps = (m_end - m_begin + WG_MSTEP * DEPTH - 1) / (WG_MSTEP * DEPTH) * DEPTH;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const short8v b = tr_frag(b_tile[cur], 0, 16 * j, lane);
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
+  for (int d = 0; d < DEPTH; ++d) fetch(d, m_begin + WG_MSTEP * d);
+  stage(0, 0);
+  fetch(0, m_begin + WG_MSTEP * DEPTH);
+  __syncthreads();
+  for (int s0 = 0; s0 < n_steps; s0 += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const bf16_t* at = a_tile0 + (d & 1) * WG_MSTEP * TN;
+      const bf16_t* bt = b_tile0 + (d & 1) * WG_MSTEP * TK;
+      short8v a[FN], b[FK];
+#pragma unroll
+      for (int i = 0; i < FN; ++i) a[i] = tr_frag<TN>(at, wave_n * (TN / 2) + 16 * i, lane);
+#pragma unroll
+      for (int j = 0; j < FK; ++j) b[j] = tr_frag<TK>(bt, wave_k * (TK / 2) + 16 * j, lane);
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      // step s+1 (ring slot (d+1) % DEPTH, loaded DEPTH steps ago) goes to the other LDS stage, which was
+      // last read one step ago (barrier below); the freed slot takes the loads of step s+1+DEPTH
+      const int slot = (d + 1) % DEPTH;
+      stage((d + 1) & 1, slot);
+      fetch(slot, m_begin + WG_MSTEP * (s0 + d + 1 + DEPTH));
+      __syncthreads();
     }
-    if (more) stage(cur ^ 1, va, vb);  // the other stage was last read one iteration ago (barrier below)
-    __syncthreads();
-    cur ^= 1;
   }
   // C/D layout of mfma_f32_16x16x32: col = lane&15, row = (lane>>4)*4 + reg
   const int col = lane & 15, rbase = (lane >> 4) * 4;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int k = k0 + 16 * j + col;
+  for (int i = 0; i < FN; ++i)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int n = n0 + 16 * wave + rbase + reg;
-      if (n < N && k < K) atomicAdd(dW + (size_t)n * ldw + k, acc[j][reg]);
+    for (int j = 0; j < FK; ++j) {
+      const int k = k0 + wave_k * (TK / 2) + 16 * j + col;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int n = n0 + wave_n * (TN / 2) + 16 * i + rbase + reg;
+        if (n < N && k < K) atomicAdd(dW + (size_t)n * ldw + k, acc[i][j][reg]);
+      }
     }
-  }
-  if (want_bias) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) bias_red[r][c8 + i] = bsum[i];
+  if (want_bias) {  // the loop ended on a barrier: the tile memory is free
+    float* red = reinterpret_cast<float*>(lds);
+    if (tid < TN) red[tid] = 0.f;
     __syncthreads();
-    if (tid < WG_TILE && n0 + tid < N) {
-      float s = 0.f;
-#pragma unroll 8
-      for (int rr = 0; rr < WG_MSTEP; ++rr) s += bias_red[rr][tid];
-      atomicAdd(db + n0 + tid, s);
-    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(red + a_j * 8 + e, bsum[e]);
+    __syncthreads();
+    if (tid < TN && n0 + tid < N) atomicAdd(db + n0 + tid, red[tid]);
   }
+}
+
+// a 128-wide tile only where it wastes no more padding than 64-wide tiles do
+static inline int tile_width(int n) { return ((n + 127) / 128 * 128 == (n + 63) / 64 * 64) ? 128 : 64; }
+
+template <bool CONV, int DEPTH>
+static int launch_wgrad(const void* dY, const void* X, float* dW, float* db, int M, int N, int K, int ldw,
+                        const ConvGeom& geom, hipStream_t stream) {
+  // Split of the M axis: all workgroups do the same amount of work, so their number should fill the
+  // chip's resident capacity (256 CUs x the tile shape's occupancy) ONCE -- 1.5 rounds cost as much as 2.
+  // Never more partial tiles than keeps the atomic traffic (chunks * N*K*4 bytes) below the operand
+  // traffic (M*(N+K)*2 bytes); chunks of at least 256 rows; a multiple of 8 chunks (one residue class
+  // per XCD). Tile shape: the largest that still fills half the capacity (128-wide tiles halve the LDS
+  // and L2 reads per MFMA but a small problem needs the parallelism more).
+  long long by_traffic = ((long long)M * (N + K)) / (2LL * N * K);
+  if (by_traffic > (M + 255) / 256) by_traffic = (M + 255) / 256;
+  if (by_traffic < 1) by_traffic = 1;
+  const int want_n = tile_width(N), want_k = tile_width(K);
+  int cand[3][2] = {{want_n, want_k}, {64, 64}, {64, 64}};
+  if (want_n == 128 && want_k == 128) cand[1][N >= K ? 0 : 1] = 128;  // halve the shorter side first
+  int tn = 64, tk = 64, n_tiles = 0, k_tiles = 0;
+  long long tiles = 0, chunks = 1;
+  for (int c = 0; c < 3; ++c) {
+    tn = cand[c][0], tk = cand[c][1];
+    n_tiles = (N + tn - 1) / tn, k_tiles = (K + tk - 1) / tk;
+    tiles = (long long)n_tiles * k_tiles;
+    const long long capacity = 256LL * (tn + tk == 256 ? 2 : tn + tk == 192 ? 3 : 4);  // __launch_bounds__(256, 2) builds
+    chunks = capacity / tiles;
+    if (chunks > by_traffic) chunks = by_traffic;
+    if (chunks >= 8) chunks = chunks / 8 * 8;
+    if (chunks < 1) chunks = 1;
+    if (tiles * chunks * 2 >= capacity) break;
+  }
+  long long m_chunk = ((long long)M + chunks - 1) / chunks;
+  m_chunk = (m_chunk + WG_MSTEP * DEPTH - 1) / (WG_MSTEP * DEPTH) * (WG_MSTEP * DEPTH);
+  const long long n_chunks = ((long long)M + m_chunk - 1) / m_chunk;
+  const long long grid = (n_chunks + 7) / 8 * 8 * tiles;
+  if (grid > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
+#define DFINE_WGRAD_LAUNCH(TN_, TK_)                                                                          \
+  hipLaunchKernelGGL((wgrad_kernel<TN_, TK_, CONV, DEPTH>), dim3((unsigned)grid), dim3(256), 0, stream,              \
+                     (const bf16_t*)dY, (const bf16_t*)X, dW, db, M, N, K, ldw, (int)m_chunk, (int)n_chunks, \
+                     k_tiles, (int)tiles, geom)
+  if (tn == 128 && tk == 128) DFINE_WGRAD_LAUNCH(128, 128);
+  else if (tn == 128) DFINE_WGRAD_LAUNCH(128, 64);
+  else if (tk == 128) DFINE_WGRAD_LAUNCH(64, 128);
+  else DFINE_WGRAD_LAUNCH(64, 64);
+#undef DFINE_WGRAD_LAUNCH
+  DFINE_LAUNCH_CHECK();
+  return 0;
 }
 
 }  // namespace dfine
 
 using namespace dfine;
 
+// prefetch depth (ring slots); DFINE_WGRAD_DEPTH=2 selects the shallow build for A/B measurements
+static int wgrad_depth() {
+  static const int depth = [] {
+    const char* e = getenv("DFINE_WGRAD_DEPTH");
+    return (e && atoi(e) == 2) ? 2 : 4;
+  }();
+  return depth;
+}
+
 extern "C" int dfine_linear_wgrad(const void* dY, const void* X, float* dW, float* db, int M, int N, int K,
                                   int ldw, void* stream) {
   if (!dY || !X || !dW) return DFINE_E_BADARG;
   if (M <= 0 || N <= 0 || K <= 0 || ldw < K) return DFINE_E_BADARG;
   if (N % 8 != 0 || K % 8 != 0) return DFINE_E_UNSUPPORTED;  // 16-byte row chunks
-  const int n_tiles = (N + WG_TILE - 1) / WG_TILE, k_tiles = (K + WG_TILE - 1) / WG_TILE;
-  // aim at ~4 workgroups per CU; chunks of >= 256 rows keep the atomic traffic below the MFMA time
-  long long chunks = 1024 / ((long long)n_tiles * k_tiles);
-  if (chunks < 1) chunks = 1;
-  long long m_chunk = ((long long)M + chunks - 1) / chunks;
-  m_chunk = (m_chunk + WG_MSTEP - 1) / WG_MSTEP * WG_MSTEP;
-  if (m_chunk < 256) m_chunk = 256;
-  const long long grid_y = ((long long)M + m_chunk - 1) / m_chunk;
-  if (grid_y > 65535) return DFINE_E_UNSUPPORTED;
-  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(n_tiles * k_tiles, (unsigned)grid_y), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)dY, (const bf16_t*)X, dW, db, M, N, K, ldw, (int)m_chunk, k_tiles);
-  DFINE_LAUNCH_CHECK();
-  return 0;
+  return wgrad_depth() == 2 ? launch_wgrad<false, 2>(dY, X, dW, db, M, N, K, ldw, ConvGeom{}, (hipStream_t)stream)
+                            : launch_wgrad<false, 4>(dY, X, dW, db, M, N, K, ldw, ConvGeom{}, (hipStream_t)stream);
+}
+
+extern "C" int dfine_conv_wgrad(const void* dY, const void* X, float* dW, int B, int H, int W, int CI, int OH,
+                                int OW, int CO, int KH, int KW, int stride, int pad, void* stream) {
+  if (!dY || !X || !dW) return DFINE_E_BADARG;
+  if (B <= 0 || H <= 0 || W <= 0 || CI <= 0 || OH <= 0 || OW <= 0 || CO <= 0 || KH <= 0 || KW <= 0 || stride <= 0 ||
+      pad < 0)
+    return DFINE_E_BADARG;
+  if (H + 2 * pad < KH || W + 2 * pad < KW || OH != (H + 2 * pad - KH) / stride + 1 || OW != (W + 2 * pad - KW) / stride + 1)
+    return DFINE_E_BADARG;  // output extent inconsistent with the input extent
+  if (CI % 8 != 0 || CO % 8 != 0) return DFINE_E_UNSUPPORTED;
+  const long long M = (long long)B * OH * OW;
+  if (M > 0x7fffffffLL - 64) return DFINE_E_UNSUPPORTED;
+  const ConvGeom geom{H, W, CI, OH, OW, KW, stride, pad};
+  const int K = KH * KW * CI;
+  if (KH == 1 && KW == 1 && stride == 1 && pad == 0)  // rows are not gathered: the Linear path
+    return wgrad_depth() == 2 ? launch_wgrad<false, 2>(dY, X, dW, nullptr, (int)M, CO, K, K, geom, (hipStream_t)stream)
+                              : launch_wgrad<false, 4>(dY, X, dW, nullptr, (int)M, CO, K, K, geom, (hipStream_t)stream);
+  return wgrad_depth() == 2 ? launch_wgrad<true, 2>(dY, X, dW, nullptr, (int)M, CO, K, K, geom, (hipStream_t)stream)
+                            : launch_wgrad<true, 4>(dY, X, dW, nullptr, (int)M, CO, K, K, geom, (hipStream_t)stream);
 }

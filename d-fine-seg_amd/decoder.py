@@ -136,6 +136,11 @@ class LQE(nn.Module):
         stat = torch.cat([top, top.mean(-1, keepdim=True)], -1).view(B, L, -1)
         return scores + self.reg_conf(stat.to(scores.dtype))
 
+    def from_stat(self, scores, stat):
+        """``stat`` [B, L, 4*(k+1)]: the statistics ``forward`` derives from the corners, precomputed by
+        ``ops.fdr_head`` together with the boxes."""
+        return scores + self.reg_conf(stat.to(scores.dtype))
+
 
 class _DecoderStack(nn.Module):  # key paths ``decoder.decoder.layers.{i}`` / ``.lqe_layers.{i}``
     def __init__(self, spec: ModelSpec, up, reg_scale):
@@ -309,13 +314,24 @@ class DFINETransformer(nn.Module):
         # ---- query selection (:840-922)
         key = ("anchors", tuple(spatial_shapes), str(dev))
         anchors, valid = self._cached(key, lambda: self.generate_anchors(spatial_shapes, dev))
-        enc_mem = self.enc_output(memory * valid.to(memory.dtype))
-        enc_logits = self.enc_score_head(enc_mem)
         topk_ind = inject.get("topk_ind")
-        if topk_ind is None:
-            topk_ind = torch.topk(enc_logits.max(-1).values, Q, dim=-1).indices
+        sink = ops.ValueGradSink() if (training and torch.is_grad_enabled()) else None
         pick = lambda t: t.gather(1, topk_ind.unsqueeze(-1).expand(-1, -1, t.shape[-1]))
-        topk_mem, topk_logits = pick(enc_mem), pick(enc_logits)
+        if sink is not None:
+            # training: all S tokens go through enc_output / the score head only to RANK them (no graph);
+            # the differentiable branch is re-run on the Q selected rows, the only ones with a gradient
+            if topk_ind is None:
+                with torch.no_grad():
+                    scores = self.enc_score_head(self.enc_output(memory * valid.to(memory.dtype))).max(-1).values
+                    topk_ind = torch.topk(scores, Q, dim=-1).indices
+            topk_mem = self.enc_output(ops.select_rows(memory, topk_ind, valid, sink))
+            topk_logits = self.enc_score_head(topk_mem)
+        else:
+            enc_mem = self.enc_output(memory * valid.to(memory.dtype))
+            enc_logits = self.enc_score_head(enc_mem)
+            if topk_ind is None:
+                topk_ind = torch.topk(enc_logits.max(-1).values, Q, dim=-1).indices
+            topk_mem, topk_logits = pick(enc_mem), pick(enc_logits)
         enc_bbox_unact = self.enc_bbox_head(topk_mem).float() + pick(anchors.expand(B, -1, -1))
         content, ref_unact = topk_mem.detach(), enc_bbox_unact.detach()
         if dn_bbox is not None:
@@ -329,20 +345,18 @@ class DFINETransformer(nn.Module):
         out, out_detach, corners_prev = content, 0, 0
         ref_detach = torch.sigmoid(ref_unact)
         boxes_l, logits_l, corners_l, hs = [], [], [], []
-        sink = ops.ValueGradSink() if (training and torch.is_grad_enabled()) else None
         for i, layer in enumerate(self.decoder.layers):
             pos = self.query_pos_head(ref_detach).clamp(-10, 10)
-            out = layer(out, ref_detach, value, spatial_shapes, blocked, pos, sink, finalize=(i == 0))
+            out = layer(out, ref_detach, value, spatial_shapes, blocked, pos, sink, finalize=False)  # select_rows finalizes
             hs.append(out)
             if i == 0:
                 pre_boxes = torch.sigmoid(self.pre_bbox_head(out).float() + inverse_sigmoid(ref_detach))
                 pre_logits = self.dec_score_head[0](out)
                 ref_initial = pre_boxes.detach()
             corners = self.dec_bbox_head[i](out + out_detach).float() + corners_prev
-            prob = torch.softmax(corners.view(B, -1, 4, spec.reg_max + 1), dim=-1)
-            box = distance2bbox(ref_initial, prob @ project, reg_scale)
+            box, stat = ops.fdr_head(corners, ref_initial, project, reg_scale, self.decoder.lqe_layers[i].k)  # HIP, fused
             if training or i == L - 1:
-                logits_l.append(self.decoder.lqe_layers[i](self.dec_score_head[i](out), corners))
+                logits_l.append(self.decoder.lqe_layers[i].from_stat(self.dec_score_head[i](out), stat))
                 boxes_l.append(box)
                 corners_l.append(corners)
             corners_prev, ref_detach, out_detach = corners, box.detach(), out.detach()

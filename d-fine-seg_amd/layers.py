@@ -73,8 +73,10 @@ class ConvNorm(nn.Module):
         conv = self.conv
         if conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1:
             x = ops.depthwise_conv2d(x, conv.weight, conv.stride[0])  # HIP: MIOpen has no fast path here
-        elif conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1:
-            x = ops.pointwise_conv(x, conv.weight)  # library fwd/dgrad, HIP wgrad straight into the fp32 grads
+        elif (conv.groups == 1 and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1]
+              and isinstance(conv.padding[0], int) and conv.dilation == (1, 1)):
+            # library fwd/dgrad, HIP wgrad straight into the fp32 grads
+            x = ops.dense_conv(x, conv.weight, conv.stride[0], conv.padding[0])
         else:
             x = conv(x)
         act_name = act if act is not None else self.act_name

@@ -118,6 +118,7 @@ class _MSDeformAttnCore(torch.autograd.Function):
         _lib.check(rc, "dfine_msda_bwd")
         if sink is not None:
             if not ctx.finalize:
+                sink.expect_consumer()
                 return None, grad_loc, grad_attn, None, None, None, None
             sink.buffer = None
         return grad_value.to(value.dtype), grad_loc, grad_attn, None, None, None, None
@@ -131,6 +132,61 @@ class ValueGradSink:
 
     def __init__(self):
         self.buffer = None
+        self._check_queued = False
+
+    def expect_consumer(self):
+        """Called from a non-finalizing backward: somebody else (``select_rows``) must take the buffer
+        before this backward pass ends. If nobody does the value gradient would be silently lost, so
+        the end-of-backward callback raises instead."""
+        if not self._check_queued:
+            self._check_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._check)
+
+    def _check(self):
+        self._check_queued = False
+        if self.buffer is not None:
+            self.buffer = None
+            raise RuntimeError("deformable attention: d(loss)/d(value) was accumulated but never handed to autograd "
+                               "(finalize=False on every call and no select_rows() on the backward path)")
+
+
+class _SelectRows(torch.autograd.Function):
+    """rows[b, j] = memory[b, idx[b, j]] * keep[idx[b, j]] -- the query-selection gather of the decoder
+    memory (reference dfine_decoder.py:885-922 gathers AFTER running enc_output / the score head on all
+    S tokens; only the selected rows ever receive a gradient, so the differentiable branch is run on the
+    selected rows alone). The gradient is added to the fp32 ``sink`` the deformable-attention calls
+    accumulate d(loss)/d(value) in -- memory IS that value tensor -- and this node, created before every
+    decoder layer and therefore run after all of them in backward (the engine runs ready nodes in
+    descending creation order), converts the total once."""
+
+    @staticmethod
+    def forward(ctx, memory, idx, keep, sink):
+        B, S, D = memory.shape
+        idx_e = idx.unsqueeze(-1).expand(-1, -1, D)
+        scale = keep.view(-1)[idx].unsqueeze(-1).to(memory.dtype)  # [B, Q, 1]
+        ctx.save_for_backward(idx_e, scale)
+        ctx.sink, ctx.shape, ctx.dtype = sink, (B, S, D), memory.dtype
+        return memory.gather(1, idx_e) * scale
+
+    @staticmethod
+    def backward(ctx, g):
+        idx_e, scale = ctx.saved_tensors
+        B, S, D = ctx.shape
+        sink = ctx.sink
+        total = sink.buffer if sink is not None else None
+        if total is None:
+            total = torch.zeros(B, S, D, dtype=torch.float32, device=g.device)
+        elif sink is not None:
+            sink.buffer = None
+        total.view(B, S, D).scatter_add_(1, idx_e, (g * scale).float())
+        return total.view(B, S, D).to(ctx.dtype), None, None, None
+
+
+def select_rows(memory, idx, keep, sink=None):
+    """memory [B, S, D], idx [B, Q] int64 (distinct per image), keep [S] (0/1) -> [B, Q, D]. With a
+    ``sink`` the deformable-attention calls on the same memory must all pass ``finalize=False``: this
+    op hands the accumulated value gradient to autograd."""
+    return _SelectRows.apply(memory, idx, keep, sink)
 
 
 def deformable_attention_core(
@@ -449,6 +505,91 @@ def criterion_head(logits, boxes, corners, ref_points, teacher_corners, teacher_
                                 float(temperature))
 
 
+class _StemPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _lib.require_gpu(x)
+        lib = _lib.load()
+        xl = _nhwc(x)
+        B, H, W, C = xl.shape
+        y = torch.empty_like(xl)
+        with _lib.timed("stem_pool_fwd", 2 * xl.numel() * xl.element_size()):
+            rc = lib.dfine_stem_pool_fwd(_lib.ptr(xl), _lib.dtype_code(xl), _lib.ptr(y), B, H, W, C, _lib.stream_ptr())
+        _lib.check(rc, "dfine_stem_pool_fwd")
+        ctx.save_for_backward(xl)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xl,) = ctx.saved_tensors
+        lib = _lib.load()
+        B, H, W, C = xl.shape
+        gyl = _nhwc(gy.to(xl.dtype))
+        gx = torch.empty_like(xl)
+        with _lib.timed("stem_pool_bwd", 3 * xl.numel() * xl.element_size()):
+            rc = lib.dfine_stem_pool_bwd(_lib.ptr(xl), _lib.ptr(gyl), _lib.dtype_code(xl), _lib.ptr(gx), B, H, W, C, _lib.stream_ptr())
+        _lib.check(rc, "dfine_stem_pool_bwd")
+        return gx.permute(0, 3, 1, 2)
+
+
+def stem_pool(x):
+    """``F.max_pool2d(F.pad(x, (0, 1, 0, 1)), 2, stride=1, ceil_mode=True)`` on a channels_last map
+    [B, C, H, W] -> [B, C, H, W] (HGNetv2 stem, hgnetv2.py:213-224), HIP, no padded copy."""
+    return _StemPool.apply(x)
+
+
+def stem_pool_supported(x):
+    return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0
+
+
+class _FdrHead(torch.autograd.Function):
+    """softmax -> Integral -> distance2bbox and the LQE statistics in one launch (csrc/fdr.hip)."""
+
+    @staticmethod
+    def forward(ctx, corners, ref_boxes, W, reg_scale, k):
+        _lib.require_gpu(corners, ref_boxes, W)
+        lib = _lib.load()
+        lead = corners.shape[:-1]
+        n_bins = W.numel()
+        c = corners.float().contiguous().view(-1, 4, n_bins)
+        r = ref_boxes.float().contiguous().view(-1, 4)
+        Wc = W.float().contiguous()
+        rows = c.shape[0]
+        boxes = torch.empty(rows, 4, dtype=torch.float32, device=c.device)
+        stat = torch.empty(rows, 4, k + 1, dtype=torch.float32, device=c.device)
+        top = torch.empty(rows, 4, k, dtype=torch.uint8, device=c.device)
+        with _lib.timed("fdr_head_fwd", c.numel() * 4 + rows * (16 + 16 + 4 * (k + 1) * 4)):
+            rc = lib.dfine_fdr_head_fwd(_lib.ptr(c), _lib.ptr(r), _lib.ptr(Wc), _lib.ptr(boxes), _lib.ptr(stat), _lib.ptr(top),
+                                        rows, n_bins, k, reg_scale, _lib.stream_ptr())
+        _lib.check(rc, "dfine_fdr_head_fwd")
+        ctx.save_for_backward(c, r, Wc, top)
+        ctx.meta = (reg_scale, k, tuple(corners.shape))
+        return boxes.view(*lead, 4), stat.view(*lead, 4 * (k + 1))
+
+    @staticmethod
+    def backward(ctx, g_boxes, g_stat):
+        c, r, Wc, top = ctx.saved_tensors
+        reg_scale, k, shape = ctx.meta
+        lib = _lib.load()
+        rows, _, n_bins = c.shape
+        gb = g_boxes.float().contiguous() if g_boxes is not None else None
+        gs = g_stat.float().contiguous() if g_stat is not None else None
+        g_corners = torch.empty_like(c)
+        with _lib.timed("fdr_head_bwd", c.numel() * 8 + rows * (16 + 16 + 4 * (k + 1) * 4)):
+            rc = lib.dfine_fdr_head_bwd(_lib.ptr(c), _lib.ptr(r), _lib.ptr(Wc), _lib.ptr(top), _lib.ptr(gb), _lib.ptr(gs),
+                                        _lib.ptr(g_corners), rows, n_bins, k, reg_scale, _lib.stream_ptr())
+        _lib.check(rc, "dfine_fdr_head_bwd")
+        return g_corners.view(shape), None, None, None, None
+
+
+def fdr_head(corners, ref_boxes, W, reg_scale, k=4):
+    """corners [..., 4*(reg_max+1)] (logits over the W(n) bins per box side), ref_boxes [..., 4] cxcywh
+    (no gradient), W [reg_max+1] -> (boxes [..., 4] cxcywh fp32, stat [..., 4*(k+1)] fp32): the
+    reference's ``distance2bbox(ref, Integral(corners), reg_scale)`` and the LQE input
+    ``cat(prob.topk(k), mean)`` (dfine_decoder.py:276-313, 487-509), differentiable w.r.t. corners."""
+    return _FdrHead.apply(corners, ref_boxes, W, float(reg_scale), int(k))
+
+
 # Accumulate Linear weight gradients straight into ``param.grad`` (the flat fp32 gradient buffer) and
 # hand autograd ``None`` for them -- the same contract as a fused wgrad-accumulate GEMM. Switched off
 # by the data-parallel reducer, which counts post-accumulate hooks to know when a bucket is complete.
@@ -491,7 +632,7 @@ class _Linear(torch.autograd.Function):
         else:
             dw = torch.zeros(N, K, dtype=torch.float32, device=x16.device)
             db = torch.zeros(N, dtype=torch.float32, device=x16.device) if bias is not None else None
-        with _lib.timed("linear_wgrad", (M * N + M * K) * 2 + N * K * 4):
+        with _lib.timed("linear_wgrad", (M * N + M * K) * 2 + N * K * 4, f"M{M} N{N} K{K}"):
             rc = lib.dfine_linear_wgrad(_lib.ptr(gy16), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), M, N, K, K, _lib.stream_ptr())
         _lib.check(rc, "dfine_linear_wgrad")
         if direct:
@@ -518,48 +659,71 @@ def linear(x, weight, bias=None, row_begin=0, row_end=None):
     return _Linear.apply(x, weight, bias, row_begin, row_end)
 
 
-class _PointwiseConv(torch.autograd.Function):
-    """1x1 stride-1 convolution on a channels_last map: forward and input gradient by the library
-    (MIOpen), weight gradient by the split-M MFMA kernel (a 1x1 conv's dW is exactly a Linear's:
-    dW[k][c] = sum over pixels of dY[pix][k] * X[pix][c]) accumulated straight into the fp32 .grad."""
+class _DenseConv(torch.autograd.Function):
+    """Dense (groups = 1, no bias) convolution on a channels_last map: forward and input gradient by the
+    library (MIOpen), weight gradient by the split-M MFMA kernel with gathered rows (for a 1x1 conv it
+    is exactly a Linear's: dW[k][c] = sum over pixels of dY[pix][k] * X[pix][c]) accumulated straight
+    into the fp32 .grad."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, stride, padding):
         w16 = weight.to(torch.bfloat16)
         x16 = x.to(torch.bfloat16)
-        y = torch.nn.functional.conv2d(x16, w16)
+        y = torch.nn.functional.conv2d(x16, w16, None, stride, padding)
         ctx.save_for_backward(x16, w16)
-        ctx.weight = weight
+        ctx.weight, ctx.geom = weight, (stride, padding)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x16, w16 = ctx.saved_tensors
         weight = ctx.weight
+        stride, padding = ctx.geom
         lib = _lib.load()
-        K_out, C_in = w16.shape[0], w16.shape[1]
+        K_out, C_in, KH, KW = w16.shape
         gy16 = gy.to(torch.bfloat16)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(gy16, x16, w16, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
-                                                     (True, False, False))[0]
-        gyl, xl = _nhwc(gy16), _nhwc(x16)  # [B,H,W,K], [B,H,W,C]: row-major [pixels, channels]
-        M = xl.numel() // C_in
+            dx = torch.ops.aten.convolution_backward(gy16, x16, w16, None, (stride, stride), (padding, padding), (1, 1),
+                                                     False, (0, 0), 1, (True, False, False))[0]
+        gyl, xl = _nhwc(gy16), _nhwc(x16)  # [B,OH,OW,K], [B,H,W,C]: row-major [pixels, channels]
+        B, H, W, _ = xl.shape
+        OH, OW = gyl.shape[1], gyl.shape[2]
+        taps = KH * KW
+        # the fp32 gradient must be laid out [K_out][KH][KW][C_in] (a channels_last weight's memory order)
         direct = (DIRECT_WGRAD_ACCUM and weight.grad is not None and weight.grad.dtype == torch.float32
-                  and weight.grad.stride()[:2] == (C_in, 1))
-        dw = weight.grad if direct else torch.zeros(K_out, C_in, 1, 1, dtype=torch.float32, device=xl.device)
-        with _lib.timed("conv1x1_wgrad", (M * K_out + M * C_in) * 2 + K_out * C_in * 4):
-            rc = lib.dfine_linear_wgrad(_lib.ptr(gyl), _lib.ptr(xl), _lib.ptr(dw), None, M, K_out, C_in, C_in, _lib.stream_ptr())
-        _lib.check(rc, "dfine_linear_wgrad")
-        return dx, (None if direct else dw.to(weight.dtype))
+                  and _is_khwc(weight.grad))
+        if direct:
+            dw = weight.grad
+        else:
+            dw = torch.zeros(K_out, C_in, KH, KW, dtype=torch.float32, device=xl.device).contiguous(memory_format=torch.channels_last)
+        M = B * OH * OW
+        with _lib.timed("conv1x1_wgrad" if taps == 1 else "conv_wgrad", (M * K_out + xl.numel()) * 2 + K_out * C_in * taps * 4,
+                        f"{B}x{H}x{W} {C_in}->{K_out} k{KH}s{stride}"):
+            rc = lib.dfine_conv_wgrad(_lib.ptr(gyl), _lib.ptr(xl), _lib.ptr(dw), B, H, W, C_in, OH, OW, K_out, KH, KW,
+                                      stride, padding, _lib.stream_ptr())
+        _lib.check(rc, "dfine_conv_wgrad")
+        return dx, (None if direct else dw.to(weight.dtype)), None, None
 
 
-def pointwise_conv(x, weight):
-    """``F.conv2d(x, weight)`` for a 1x1 stride-1 conv without bias on a channels_last map. In bf16
-    training mode the weight gradient comes from the HIP split-M kernel (no MIOpen fp32 workspace,
-    cast and accumulate launches); otherwise this is plain ``F.conv2d``."""
+def _is_khwc(t):
+    """True when the 4-d weight-shaped tensor ``t`` [K, C, KH, KW] is dense in [K][KH][KW][C] order."""
+    K, C, KH, KW = t.shape
+    want = (KH * KW * C, 1, KW * C, C)
+    return all(t.shape[d] == 1 or t.stride(d) == want[d] for d in range(4))
+
+
+def dense_conv(x, weight, stride=1, padding=0):
+    """``F.conv2d(x, weight, None, stride, padding)`` for a groups=1 conv without bias on a
+    channels_last map. In bf16 training mode the weight gradient comes from the HIP split-M kernel (no
+    MIOpen fp32 workspace, cast and accumulate launches); otherwise this is plain ``F.conv2d``."""
     k_out, c_in = weight.shape[0], weight.shape[1]
     bf16_mode = x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16)
     if not bf16_mode or k_out % 8 or c_in % 8 or not (weight.requires_grad and torch.is_grad_enabled()):
-        return torch.nn.functional.conv2d(x, weight)
-    return _PointwiseConv.apply(x, weight)
+        return torch.nn.functional.conv2d(x, weight, None, stride, padding)
+    return _DenseConv.apply(x, weight, int(stride), int(padding))
+
+
+def pointwise_conv(x, weight):
+    """1x1 stride-1 ``dense_conv``."""
+    return dense_conv(x, weight, 1, 0)

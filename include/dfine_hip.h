@@ -218,6 +218,52 @@ int dfine_criterion_head(const void* logits, int logits_dtype, const float* boxe
 int dfine_linear_wgrad(const void* dY, const void* X, float* dW, float* db, int M, int N, int K, int ldw,
                        void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Weight gradient of a dense (groups = 1, no bias) 2-d convolution on channels_last maps (autograd
+ * of the nn.Conv2d inside ConvBNAct, src/d_fine/arch/hgnetv2.py:35-80, and ConvNormLayer,
+ * hybrid_encoder.py:21-93), same split-M MFMA kernel with gathered X rows:
+ *     dW[n][ky][kx][c] += sum_{b,oy,ox} dY[b][oy][ox][n] * X[b][oy*stride-pad+ky][ox*stride-pad+kx][c]
+ *   dY [B, OH, OW, CO] bf16, X [B, H, W, CI] bf16 (NHWC memory); dW f32 [CO][KH][KW][CI] -- the memory
+ *   order of a channels_last weight -- ACCUMULATED with float atomics (point it at the fp32 gradient
+ *   or at zeroed scratch). OH/OW must equal (H + 2*pad - KH) / stride + 1 (resp. W, KW).
+ *   Needs CI % 8 == 0 and CO % 8 == 0.
+ * ------------------------------------------------------------------------------------- */
+int dfine_conv_wgrad(const void* dY, const void* X, float* dW, int B, int H, int W, int CI, int OH, int OW,
+                     int CO, int KH, int KW, int stride, int pad, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * FDR head of one decoder layer (reference src/d_fine/arch/dfine_decoder.py:276-296 Integral,
+ * :298-313 LQE, :487-509 where the decoder applies them; arch/utils.py:119-142 distance2bbox):
+ *     p        = softmax(corners[row][side][:])                         side in {l, t, r, b}
+ *     d[side]  = sum_j p_j * W[j]                                        F.linear(prob, project)
+ *     boxes    = distance2bbox(ref_boxes[row], d, |reg_scale|)           cxcywh
+ *     stat     = (top-k values of p in descending order, their mean)     prob.topk(k) ++ mean
+ *   corners f32 [rows, 4, n_bins], ref_boxes f32 [rows, 4] (cxcywh), W f32 [n_bins]
+ *   boxes f32 [rows, 4], stat f32 [rows, 4, k+1], top_idx u8 [rows, 4, k] (bins of the top-k, kept
+ *   for the backward). k must be 4 (LQE(4, ...), :598); 4 <= n_bins <= 255.
+ * Backward: g_boxes f32 [rows, 4] and g_stat f32 [rows, 4, k+1] (either may be NULL = zero)
+ *   -> g_corners f32 [rows, 4, n_bins] (written, not accumulated). ref_boxes and W get no gradient
+ *   (the decoder detaches the reference boxes; up / reg_scale are frozen Parameters, :592-593).
+ * ------------------------------------------------------------------------------------- */
+int dfine_fdr_head_fwd(const float* corners, const float* ref_boxes, const float* W, float* boxes, float* stat,
+                       unsigned char* top_idx, long long rows, int n_bins, int k, float reg_scale, void* stream);
+int dfine_fdr_head_bwd(const float* corners, const float* ref_boxes, const float* W, const unsigned char* top_idx,
+                       const float* g_boxes, const float* g_stat, float* g_corners, long long rows, int n_bins,
+                       int k, float reg_scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Stem pooling of HGNetv2 (reference src/d_fine/arch/hgnetv2.py:213-224):
+ *     y = F.max_pool2d(F.pad(x, (0, 1, 0, 1)), kernel_size=2, stride=1, ceil_mode=True)
+ * on a channels_last map, without the padded copy: the map is read as zero-extended by one row and
+ * one column at the bottom/right, so y keeps x's extent.
+ *   x, y, gy, gx [B, H, W, C] bf16 or f32 (dtype); C % 8 == 0 (bf16) / C % 4 == 0 (f32).
+ * Backward sends each output gradient to the first maximum of its window in scan order (ATen's
+ * rule); gradients that fall on the zero extension are dropped. gx is written, not accumulated.
+ * ------------------------------------------------------------------------------------- */
+int dfine_stem_pool_fwd(const void* x, int dtype, void* y, int B, int H, int W, int C, void* stream);
+int dfine_stem_pool_bwd(const void* x, const void* gy, int dtype, void* gx, int B, int H, int W, int C,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,6 @@
-"""Split-M MFMA weight/bias-gradient kernel of Linear layers against a plain PyTorch fp32 reference
-of the same contraction (dW = dY^T X, db = sum dY on the bf16-rounded operands, fp32 math)."""
+"""Split-M MFMA weight/bias-gradient kernel of Linear layers and dense convolutions against a plain
+PyTorch fp32 reference of the same contraction (dW = dY^T X, db = sum dY; conv: autograd of F.conv2d --
+on the bf16-rounded operands, fp32 math)."""
 import pytest
 import torch
 
@@ -7,7 +8,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("M,N,K", [(15744, 1024, 256), (15744, 256, 1024), (15744, 80, 256), (15744, 192, 256),
-                                   (268800, 256, 256), (12800, 256, 256), (1000, 8, 8), (33, 72, 136), (1, 64, 64)])
+                                   (268800, 256, 256), (12800, 256, 256), (1000, 8, 8), (33, 72, 136), (1, 64, 64),
+                                   # every tile shape: 128x128, 128x64, 64x128 (and the fallback to smaller tiles)
+                                   (40000, 128, 128), (40000, 384, 64), (40000, 64, 384), (300000, 128, 256),
+                                   (2000, 256, 256), (700, 136, 264)])
 def test_linear_wgrad_matches_fp32_reference(hip_lib, M, N, K):
     from dfine_seg_amd import _lib
 
@@ -86,4 +90,73 @@ def test_pointwise_conv_matches_torch(hip_lib):
         y.backward(gy)
         torch.testing.assert_close(y.float(), F.conv2d(xr, wr).detach(), rtol=2e-2, atol=2e-2)
         torch.testing.assert_close(xd.grad.float(), xr.grad, rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(wd.grad, wr.grad, rtol=1e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize("B,H,W,CI,CO,k,stride,pad", [
+    (2, 40, 40, 32, 32, 3, 1, 1),    # HG-block 3x3
+    (3, 23, 17, 64, 48, 3, 1, 1),    # ragged extent, borders everywhere
+    (2, 40, 36, 32, 64, 3, 2, 1),    # stem3 style stride 2
+    (2, 33, 33, 16, 16, 2, 1, 0),    # stem2a/2b style 2x2 without padding
+    (2, 20, 20, 128, 128, 3, 1, 1),  # RepVgg 3x3: K = 1152, 128-wide tiles
+    (4, 80, 80, 64, 64, 3, 1, 1),    # many pixels: several m-chunks
+    (2, 20, 20, 256, 64, 1, 1, 0),   # 1x1 through the conv entry
+    (1, 9, 9, 8, 8, 5, 1, 2),        # 5x5, tiny
+    (2, 16, 16, 24, 40, 3, 1, 1),    # channel counts that are multiples of 8 only
+])
+def test_conv_wgrad_matches_fp32_reference(hip_lib, B, H, W, CI, CO, k, stride, pad):
+    import torch.nn.functional as F
+
+    from dfine_seg_amd import _lib
+
+    g = torch.Generator(device="cuda").manual_seed(B * H + CI + CO + k)
+    x = torch.randn(B, CI, H, W, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    gy = torch.randn(B, CO, OH, OW, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(CO, CI, k, k, device="cuda", requires_grad=True)
+    F.conv2d(x.float(), w, None, stride, pad).backward(gy.float())
+    dw = torch.zeros(CO, k, k, CI, device="cuda")  # [K][KH][KW][C]
+    rc = hip_lib.dfine_conv_wgrad(_lib.ptr(gy.permute(0, 2, 3, 1)), _lib.ptr(x.permute(0, 2, 3, 1)), _lib.ptr(dw),
+                                  B, H, W, CI, OH, OW, CO, k, k, stride, pad, _lib.stream_ptr())
+    assert rc == 0
+    M = B * OH * OW
+    tol = (3e-8 * M + 2e-4) * 4
+    torch.testing.assert_close(dw.permute(0, 3, 1, 2), w.grad, rtol=1e-4, atol=tol)
+
+
+def test_conv_wgrad_rejects_inconsistent_geometry(hip_lib):
+    from dfine_seg_amd import _lib
+
+    t = torch.zeros(1, 8, 8, 8, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros(8, 3, 3, 8, device="cuda")
+    # 8x8 input, 3x3 pad 1 stride 1 gives 8x8, not 7x7
+    assert hip_lib.dfine_conv_wgrad(_lib.ptr(t), _lib.ptr(t), _lib.ptr(out), 1, 8, 8, 8, 7, 7, 8, 3, 3, 1, 1, None) == -1
+    t12 = torch.zeros(1, 8, 8, 12, device="cuda", dtype=torch.bfloat16)
+    assert hip_lib.dfine_conv_wgrad(_lib.ptr(t), _lib.ptr(t12), _lib.ptr(out), 1, 8, 8, 12, 8, 8, 8, 3, 3, 1, 1, None) == -2
+
+
+@pytest.mark.parametrize("k,stride,pad", [(3, 1, 1), (3, 2, 1), (2, 1, 0)])
+def test_dense_conv_matches_torch(hip_lib, k, stride, pad):
+    """kxk conv through ops.dense_conv (bf16 mode) vs F.conv2d autograd in fp32 on the same values, with
+    the gradient accumulated into a channels_last fp32 .grad and returned through autograd."""
+    import torch.nn.functional as F
+
+    from dfine_seg_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(11 + k)
+    x = torch.randn(2, 32, 22, 26, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(48, 32, k, k, device="cuda", generator=g) * 0.1).contiguous(memory_format=torch.channels_last)
+    xr, wr = x.float().requires_grad_(True), w.bfloat16().float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, pad)
+    gy = torch.randn(yr.shape, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    yr.backward(gy.float())
+    for direct in (True, False):
+        xd, wd = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        if direct:
+            wd.grad = torch.zeros_like(wd)
+            assert wd.grad.is_contiguous(memory_format=torch.channels_last)
+        y = ops.dense_conv(xd, wd, stride, pad)
+        y.backward(gy)
+        torch.testing.assert_close(y.float(), yr.detach(), rtol=2e-2, atol=3e-2)
+        torch.testing.assert_close(xd.grad.float(), xr.grad, rtol=2e-2, atol=3e-2)
         torch.testing.assert_close(wd.grad, wr.grad, rtol=1e-3, atol=3e-3)
