@@ -596,17 +596,30 @@ def fdr_head(corners, ref_boxes, W, reg_scale, k=4):
 DIRECT_WGRAD_ACCUM = True
 
 
+def bf16_of(param):
+    """bf16 value of an fp32 master parameter: the optimizer-maintained shadow copy when there is one and
+    it is current (optim.FlatState.enable_bf16_shadow), else a cast."""
+    shadow = getattr(param, "_bf16_shadow", None)
+    if shadow is not None and param._shadow_version == param._version:
+        return shadow
+    return param.to(torch.bfloat16)
+
+
 class _Linear(torch.autograd.Function):
     """y = x @ W[rows]^T + b[rows] in bf16 (hipBLASLt), with the weight/bias gradient by the split-M
     MFMA kernel dfine_linear_wgrad."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, row_begin, row_end):
-        w = weight[row_begin:row_end]
-        b = bias[row_begin:row_end] if bias is not None else None
+        whole = row_begin == 0 and row_end == weight.shape[0]
         x16 = x.to(torch.bfloat16)
-        w16 = w.to(torch.bfloat16)
-        y = torch.nn.functional.linear(x16, w16, b.to(torch.bfloat16) if b is not None else None)
+        if whole or getattr(weight, "_bf16_shadow", None) is not None:
+            w16 = bf16_of(weight)[row_begin:row_end]
+            b16 = bf16_of(bias)[row_begin:row_end] if bias is not None else None
+        else:  # no shadow: cast only the rows used
+            w16 = weight[row_begin:row_end].to(torch.bfloat16)
+            b16 = bias[row_begin:row_end].to(torch.bfloat16) if bias is not None else None
+        y = torch.nn.functional.linear(x16, w16, b16)
         ctx.save_for_backward(x16, w16)
         ctx.params = (weight, bias, row_begin, row_end)
         return y
@@ -667,7 +680,7 @@ class _DenseConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, stride, padding):
-        w16 = weight.to(torch.bfloat16)
+        w16 = bf16_of(weight)
         x16 = x.to(torch.bfloat16)
         y = torch.nn.functional.conv2d(x16, w16, None, stride, padding)
         ctx.save_for_backward(x16, w16)

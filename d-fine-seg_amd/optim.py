@@ -61,12 +61,34 @@ class FlatState:
         self.device = device
         self.params = torch.zeros(offset, dtype=torch.float32, device=device)
         self.grads = torch.zeros(offset, dtype=torch.float32, device=device)
+        self.shadow = None  # bf16 copy of params, see enable_bf16_shadow()
         with torch.no_grad():
             for name, p, off, n, _ in self.entries:
                 home = self.view_like(self.params, p, off)
                 home.copy_(p.data)
                 p.data = home
                 p.grad = self.view_like(self.grads, p, off)
+
+    def enable_bf16_shadow(self):
+        """Keep a bf16 copy of every parameter in one flat buffer, refreshed by the fused optimizer
+        kernel as it writes the fp32 value (2 more bytes per parameter in a launch that moves 40), and
+        hang each parameter's view of it on the Parameter (``_bf16_shadow``): the bf16 compute path
+        (``ops.linear`` / ``ops.dense_conv``) then reads the copy instead of casting the fp32 master
+        weight in ~300 small launches per step. A parameter changed behind the optimizer's back (its
+        ``_version`` moved: ``load_state_dict``, ``copy_``) is cast again until ``refresh_bf16_shadow``."""
+        self.shadow = torch.empty(self.numel, dtype=torch.bfloat16, device=self.device)
+        self.refresh_bf16_shadow()
+
+    def refresh_bf16_shadow(self):
+        if self.shadow is None:
+            return
+        self.shadow.copy_(self.params)
+        for name, p, off, n, _ in self.entries:
+            p._bf16_shadow = self.view_like(self.shadow, p, off)
+            p._shadow_version = p._version
+
+    def bf16_shadow_is_current(self):
+        return self.shadow is None or all(p._shadow_version == p._version for _, p, _, _, _ in self.entries)
 
     @staticmethod
     def view_like(flat, p, offset):
@@ -135,9 +157,10 @@ class FusedAdamWEMA:
         with _lib.timed("grad_sumsq", f.numel * 4):
             _lib.check(lib.dfine_grad_sumsq(_lib.ptr(f.grads), f.numel, _lib.ptr(self.sumsq), st), "dfine_grad_sumsq")
         n_streams = 8 + (2 if self.ema_flat is not None else 0)  # p,g,m,v read and written (+ ema read and written)
-        with _lib.timed("adamw_ema_step", f.numel * 4 * n_streams):
+        shadow_bytes = f.numel * 2 if f.shadow is not None else 0
+        with _lib.timed("adamw_ema_step", f.numel * 4 * n_streams + shadow_bytes):
             rc = lib.dfine_adamw_ema_step(_lib.ptr(f.params), _lib.ptr(f.grads), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
-                                          _lib.ptr(self.ema_flat), None, _lib.ptr(self.hyper), _lib.ptr(self.sumsq),
+                                          _lib.ptr(self.ema_flat), _lib.ptr(f.shadow), _lib.ptr(self.hyper), _lib.ptr(self.sumsq),
                                           self._group_begin, len(f.group_begin), f.numel, st)
         _lib.check(rc, "dfine_adamw_ema_step")
 

@@ -75,6 +75,8 @@ class TrainStep:
         self.criterion = build_loss(model_name, num_classes, 0.0, enable_mask_head)
         self.ema = ModelEMA(self.model, ema_momentum) if use_ema else None
         self.flat = FlatState(self.model)
+        if amp:
+            self.flat.enable_bf16_shadow()
         ema_flat = self.flat.mirror(self.ema.model) if self.ema is not None else None
         # groups and max learning rates as in train.py:184-208 (OneCycle peaks at 2x the configured lr)
         self.max_lrs = {"backbone": backbone_lr * 2, "backbone_norm": backbone_lr * 2,
@@ -127,6 +129,8 @@ class TrainStep:
         tb = TargetBatch.from_list(targets, self.num_classes, self.device)
         images = images.to(self.device, non_blocking=True)
         self._schedule()
+        if not self.flat.bf16_shadow_is_current():  # weights were written behind the optimizer's back (load_state_dict, ...)
+            self.flat.refresh_bf16_shadow()
         if not self.use_graph or tb.masks is not None or self.iters <= self.graph_warmup:
             return self._body(images, tb)
         key = (tuple(images.shape), tb.max_gt, max(tb.num_gts), tb.total > 0)

@@ -118,3 +118,34 @@ def test_graph_replay_matches_eager(hip_lib):
         assert (len(t._graphs) == 1) == use_graph
     for a, b in zip(losses[False], losses[True]):
         assert abs(a - b) <= 2e-3 * abs(a), (losses[False], losses[True])
+
+
+@pytest.mark.gpu
+def test_bf16_shadow_follows_the_master_weights(hip_lib):
+    """The optimizer kernel keeps the bf16 copy the compute path reads equal to bf16(fp32 master); a
+    weight written behind its back is detected (tensor version) and served by a cast until refreshed."""
+    from dfine_seg_amd import ops
+    from dfine_seg_amd.optim import FlatState, FusedAdamWEMA
+
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(16, 24), torch.nn.Linear(24, 8)).cuda()
+    flat = FlatState(model)
+    flat.enable_bf16_shadow()
+    groups = {g: 1e-2 for g in flat.group_names}
+    opt = FusedAdamWEMA(flat, groups, {g: 0.0 for g in flat.group_names})
+    w = model[0].weight
+    assert ops.bf16_of(w).data_ptr() == w._bf16_shadow.data_ptr()
+    for _ in range(3):
+        flat.grads.normal_()
+        opt.step()
+        torch.cuda.synchronize()
+        assert torch.equal(flat.shadow, flat.params.to(torch.bfloat16))
+        assert torch.equal(ops.bf16_of(w), w.detach().to(torch.bfloat16))
+        assert ops.bf16_of(w).data_ptr() == w._bf16_shadow.data_ptr()  # no cast launched
+    with torch.no_grad():
+        w.add_(1.0)  # e.g. load_state_dict
+    assert not flat.bf16_shadow_is_current()
+    assert torch.equal(ops.bf16_of(w), w.detach().to(torch.bfloat16))  # served by a cast, not the stale copy
+    flat.refresh_bf16_shadow()
+    assert flat.bf16_shadow_is_current() and ops.bf16_of(w).data_ptr() == w._bf16_shadow.data_ptr()
+    assert torch.equal(flat.shadow, flat.params.to(torch.bfloat16))
