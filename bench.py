@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--task", default="detect", choices=["detect", "segment"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run every step eagerly (no hipGraph capture)")
+    ap.add_argument("--no-miopen-find", action="store_true",
+                    help="leave torch.backends.cudnn.benchmark off (MIOpen then picks conv solvers by heuristic: ~13 %% slower steps, ~2 min less warm-up)")
     ap.add_argument("--shapes", action="store_true", help="diagnostic: key the per-kernel timings by operand shape")
     return ap.parse_args()
 
@@ -109,6 +111,10 @@ def main():
         from dfine_seg_amd.ddp import BucketedGradReducer
 
         reducer = BucketedGradReducer
+    # the library convolutions (dense conv forward / input gradient): let MIOpen time its solvers once per
+    # shape during the warm-up steps instead of trusting its heuristic (which favours split-K kernels that
+    # need a zeroed fp32 workspace and a cast launch around them)
+    torch.backends.cudnn.benchmark = not args.no_miopen_find
     torch.manual_seed(42 + rank)  # per-rank seed like train.py:131
     trainer = TrainStep(args.model, 80, seg, (args.img, args.img), device, total_steps=max(1000, args.steps + args.warmup + 1),
                         grad_reducer=reducer, use_graph=not args.no_graph)
