@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="run every step eagerly (no hipGraph capture)")
     ap.add_argument("--no-miopen-find", action="store_true",
                     help="leave torch.backends.cudnn.benchmark off (MIOpen then picks conv solvers by heuristic: ~13 %% slower steps, ~2 min less warm-up)")
+    ap.add_argument("--bucketed-reducer", action="store_true",
+                    help="N>1: eager step + bucketed all-reduce overlapped with backward (default: captured graphs + one flat all-reduce)")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="diagnostic: take the N>1 code path (process group, reducer, split graphs) even with one rank")
     ap.add_argument("--shapes", action="store_true", help="diagnostic: key the per-kernel timings by operand shape")
     return ap.parse_args()
 
@@ -95,7 +99,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_ddp:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
 
     import __graft_entry__
@@ -107,10 +113,12 @@ def main():
 
     seg = args.task == "segment"
     reducer = None
-    if world > 1:
-        from dfine_seg_amd.ddp import BucketedGradReducer
+    if world > 1 or args.force_ddp:
+        from dfine_seg_amd import ddp
 
-        reducer = BucketedGradReducer
+        # default: hipGraph(forward+backward) -> one flat RCCL all-reduce -> hipGraph(optimizer);
+        # --bucketed-reducer: eager step with bucket all-reduces overlapping backward on a side stream
+        reducer = ddp.BucketedGradReducer if args.bucketed_reducer else ddp.FlatGradAllReduce
     # the library convolutions (dense conv forward / input gradient): let MIOpen time its solvers once per
     # shape during the warm-up steps instead of trusting its heuristic (which favours split-K kernels that
     # need a zeroed fp32 workspace and a cast launch around them)
@@ -188,7 +196,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(trainer.model, args)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

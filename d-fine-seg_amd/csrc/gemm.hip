@@ -58,6 +58,26 @@ __device__ __forceinline__ short8v tr_frag(const bf16_t* tile, int col0, int lan
   return f;
 }
 
+// 8 consecutive bf16 from a 4-byte aligned address; only the first `valid` (1..8) are read, the rest are 0
+struct __attribute__((packed, aligned(4))) Vec16u {
+  uint32_t w[4];
+};
+template <bool EDGE>
+__device__ __forceinline__ Vec16 load_chunk(const bf16_t* __restrict__ p, int valid) {
+  Vec16 v;
+  if (!EDGE || valid == 8) {
+    const Vec16u u = *reinterpret_cast<const Vec16u*>(p);
+    v.w[0] = u.w[0], v.w[1] = u.w[1], v.w[2] = u.w[2], v.w[3] = u.w[3];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t lo = 2 * i < valid ? p[2 * i] : 0u, hi = 2 * i + 1 < valid ? p[2 * i + 1] : 0u;
+      v.w[i] = lo | (hi << 16);
+    }
+  }
+  return v;
+}
+
 struct ConvGeom {
   int H, W, CI, OH, OW, KW, stride, pad;
 };
@@ -80,7 +100,7 @@ struct PixelCursor {
   }
 };
 
-template <int TN, int TK, bool CONV, int DEPTH>
+template <int TN, int TK, bool CONV, int DEPTH, bool EDGE>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
                                                     float* __restrict__ dW, float* __restrict__ db, int M, int N,
                                                     int K, int ldw, int m_chunk, int n_chunks, int k_tiles,
@@ -108,7 +128,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict_
   const int a_r = tid / A_CPR, a_j = tid % A_CPR;  // further rows at +256/A_CPR
   const int b_r = tid / B_CPR, b_j = tid % B_CPR;
   constexpr int A_RSTEP = 256 / A_CPR, B_RSTEP = 256 / B_CPR;
-  const bool a_cols = n0 + a_j * 8 < N, b_cols = k0 + b_j * 8 < K;  // N, K multiples of 8: all in or all out
+  // valid elements of this thread's 8-column chunks (N, K need not be multiples of 8: the last chunk of a
+  // row may be partial; rows are then only 4-byte aligned, which a global dwordx4 load does not mind)
+  const int a_valid = min(max(N - (n0 + a_j * 8), 0), 8), b_valid = min(max(K - (k0 + b_j * 8), 0), 8);
   int tap_dy = 0, tap_dx = 0, chan = 0;
   PixelCursor cur_px[B_ROWS];
   if (CONV) {
@@ -139,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict_
     for (int i = 0; i < A_ROWS; ++i) {
       const int m = m0 + a_r + i * A_RSTEP;
       va[slot][i].w[0] = va[slot][i].w[1] = va[slot][i].w[2] = va[slot][i].w[3] = 0u;
-      if (m < m_end && a_cols) va[slot][i] = *reinterpret_cast<const Vec16*>(dY + (size_t)m * N + n0 + a_j * 8);
+      if (m < m_end && a_valid > 0) va[slot][i] = load_chunk<EDGE>(dY + (size_t)m * N + n0 + a_j * 8, a_valid);
     }
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) {
@@ -147,11 +169,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict_
       vb[slot][i].w[0] = vb[slot][i].w[1] = vb[slot][i].w[2] = vb[slot][i].w[3] = 0u;
       if (CONV) {
         const int iy = cur_px[i].oy * geom.stride + tap_dy, ix = cur_px[i].ox * geom.stride + tap_dx;
-        if (m < m_end && b_cols && (unsigned)iy < (unsigned)geom.H && (unsigned)ix < (unsigned)geom.W)
-          vb[slot][i] = *reinterpret_cast<const Vec16*>(X + (((size_t)cur_px[i].b * geom.H + iy) * geom.W + ix) * geom.CI + chan);
+        if (m < m_end && b_valid > 0 && (unsigned)iy < (unsigned)geom.H && (unsigned)ix < (unsigned)geom.W)
+          vb[slot][i] = load_chunk<false>(X + (((size_t)cur_px[i].b * geom.H + iy) * geom.W + ix) * geom.CI + chan, 8);
         cur_px[i].advance(geom);
       } else {
-        if (m < m_end && b_cols) vb[slot][i] = *reinterpret_cast<const Vec16*>(X + (size_t)m * K + k0 + b_j * 8);
+        if (m < m_end && b_valid > 0) vb[slot][i] = load_chunk<EDGE>(X + (size_t)m * K + k0 + b_j * 8, b_valid);
       }
     }
   };
@@ -234,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict_
 // a 128-wide tile only where it wastes no more padding than 64-wide tiles do
 static inline int tile_width(int n) { return ((n + 127) / 128 * 128 == (n + 63) / 64 * 64) ? 128 : 64; }
 
-template <bool CONV, int DEPTH>
+template <bool CONV, int DEPTH, bool EDGE>
 static int launch_wgrad(const void* dY, const void* X, float* dW, float* db, int M, int N, int K, int ldw,
                         const ConvGeom& geom, hipStream_t stream) {
   // Split of the M axis: all workgroups do the same amount of work, so their number should fill the
@@ -268,7 +290,7 @@ static int launch_wgrad(const void* dY, const void* X, float* dW, float* db, int
   const long long grid = (n_chunks + 7) / 8 * 8 * tiles;
   if (grid > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
 #define DFINE_WGRAD_LAUNCH(TN_, TK_)                                                                          \
-  hipLaunchKernelGGL((wgrad_kernel<TN_, TK_, CONV, DEPTH>), dim3((unsigned)grid), dim3(256), 0, stream,              \
+  hipLaunchKernelGGL((wgrad_kernel<TN_, TK_, CONV, DEPTH, EDGE>), dim3((unsigned)grid), dim3(256), 0, stream,              \
                      (const bf16_t*)dY, (const bf16_t*)X, dW, db, M, N, K, ldw, (int)m_chunk, (int)n_chunks, \
                      k_tiles, (int)tiles, geom)
   if (tn == 128 && tk == 128) DFINE_WGRAD_LAUNCH(128, 128);
@@ -293,13 +315,24 @@ static int wgrad_depth() {
   return depth;
 }
 
+// EDGE builds carry the element-wise path for a partial last chunk (N or K not a multiple of 8)
+template <bool CONV>
+static int dispatch_wgrad(const void* dY, const void* X, float* dW, float* db, int M, int N, int K, int ldw,
+                          const ConvGeom& geom, hipStream_t stream) {
+  const bool edge = N % 8 != 0 || K % 8 != 0;
+  if (wgrad_depth() == 2)
+    return edge ? launch_wgrad<CONV, 2, true>(dY, X, dW, db, M, N, K, ldw, geom, stream)
+                : launch_wgrad<CONV, 2, false>(dY, X, dW, db, M, N, K, ldw, geom, stream);
+  return edge ? launch_wgrad<CONV, 4, true>(dY, X, dW, db, M, N, K, ldw, geom, stream)
+              : launch_wgrad<CONV, 4, false>(dY, X, dW, db, M, N, K, ldw, geom, stream);
+}
+
 extern "C" int dfine_linear_wgrad(const void* dY, const void* X, float* dW, float* db, int M, int N, int K,
                                   int ldw, void* stream) {
   if (!dY || !X || !dW) return DFINE_E_BADARG;
   if (M <= 0 || N <= 0 || K <= 0 || ldw < K) return DFINE_E_BADARG;
-  if (N % 8 != 0 || K % 8 != 0) return DFINE_E_UNSUPPORTED;  // 16-byte row chunks
-  return wgrad_depth() == 2 ? launch_wgrad<false, 2>(dY, X, dW, db, M, N, K, ldw, ConvGeom{}, (hipStream_t)stream)
-                            : launch_wgrad<false, 4>(dY, X, dW, db, M, N, K, ldw, ConvGeom{}, (hipStream_t)stream);
+  if (N % 2 != 0 || K % 2 != 0) return DFINE_E_UNSUPPORTED;  // rows must stay 4-byte aligned
+  return dispatch_wgrad<false>(dY, X, dW, db, M, N, K, ldw, ConvGeom{}, (hipStream_t)stream);
 }
 
 extern "C" int dfine_conv_wgrad(const void* dY, const void* X, float* dW, int B, int H, int W, int CI, int OH,
@@ -310,14 +343,12 @@ extern "C" int dfine_conv_wgrad(const void* dY, const void* X, float* dW, int B,
     return DFINE_E_BADARG;
   if (H + 2 * pad < KH || W + 2 * pad < KW || OH != (H + 2 * pad - KH) / stride + 1 || OW != (W + 2 * pad - KW) / stride + 1)
     return DFINE_E_BADARG;  // output extent inconsistent with the input extent
-  if (CI % 8 != 0 || CO % 8 != 0) return DFINE_E_UNSUPPORTED;
+  if (CI % 8 != 0 || CO % 2 != 0) return DFINE_E_UNSUPPORTED;  // an 8-column chunk must not straddle two taps
   const long long M = (long long)B * OH * OW;
   if (M > 0x7fffffffLL - 64) return DFINE_E_UNSUPPORTED;
   const ConvGeom geom{H, W, CI, OH, OW, KW, stride, pad};
   const int K = KH * KW * CI;
   if (KH == 1 && KW == 1 && stride == 1 && pad == 0)  // rows are not gathered: the Linear path
-    return wgrad_depth() == 2 ? launch_wgrad<false, 2>(dY, X, dW, nullptr, (int)M, CO, K, K, geom, (hipStream_t)stream)
-                              : launch_wgrad<false, 4>(dY, X, dW, nullptr, (int)M, CO, K, K, geom, (hipStream_t)stream);
-  return wgrad_depth() == 2 ? launch_wgrad<true, 2>(dY, X, dW, nullptr, (int)M, CO, K, K, geom, (hipStream_t)stream)
-                            : launch_wgrad<true, 4>(dY, X, dW, nullptr, (int)M, CO, K, K, geom, (hipStream_t)stream);
+    return dispatch_wgrad<false>(dY, X, dW, nullptr, (int)M, CO, K, K, geom, (hipStream_t)stream);
+  return dispatch_wgrad<true>(dY, X, dW, nullptr, (int)M, CO, K, K, geom, (hipStream_t)stream);
 }

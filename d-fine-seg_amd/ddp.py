@@ -13,6 +13,15 @@ C1-C3 in SURVEY.md 2.3).
     raise on the following iteration instead;
   * parameters are broadcast from rank 0 once; BatchNorm statistics stay per-rank (DDP re-broadcasts
     all buffers every forward, C3).
+
+Two exchange schedules over the same flat buffer:
+
+  * ``FlatGradAllReduce`` (bench.py's default for N > 1): forward+backward and the optimizer tail are
+    each ONE captured hipGraph; between the two replays the whole gradient buffer is averaged with a
+    single RCCL all-reduce (78 MB for D-FINE-m: ~2-3 ms over xGMI against a ~50 ms step). No overlap
+    with backward, but no per-kernel launch cost either -- eager launching costs this model ~40 ms of
+    host time per step, far more than the exposed collective;
+  * ``BucketedGradReducer``: eager step, buckets reduced on a side stream as backward fills them.
 """
 import os
 
@@ -134,6 +143,49 @@ class BucketedGradReducer:
             if self.on_gpu:
                 torch.cuda.current_stream().wait_stream(self.side_stream)
             b.work, b.pending = None, len(b.params)
+
+    def zero_grad(self):
+        self.flat.grads.zero_()
+
+
+class FlatGradAllReduce:
+    """Average the flat gradient buffer over the ranks with one collective, between the captured
+    forward/backward graph and the captured optimizer graph (``train.TrainStep`` replays
+    graph A -> ``reduce()`` -> graph B). ``num_chunks`` > 1 splits the message (contiguous ranges)."""
+
+    graph_safe = True  # TrainStep may capture around it: the collective itself is never inside a capture
+
+    def __init__(self, model, num_chunks=1, process_group=None, broadcast_parameters=True):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("FlatGradAllReduce needs an initialised process group")
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.flat = model if isinstance(model, FlatState) else FlatState(model)
+        tensors = [self.flat.params]
+        if not isinstance(model, FlatState):
+            tensors += [b for b in model.buffers()] + [p for p in model.parameters() if not p.requires_grad]
+        self.backend_has_avg = dist.get_backend(process_group) == "nccl"
+        if broadcast_parameters:
+            with torch.no_grad():
+                for t in tensors:
+                    dist.broadcast(t, src=0, group=process_group)
+            self.flat.refresh_bf16_shadow()
+        n = self.flat.numel
+        step = (n + num_chunks - 1) // max(num_chunks, 1)
+        step = (step + 3) // 4 * 4
+        self.chunks = [self.flat.grads[i : min(i + step, n)] for i in range(0, n, step)]
+
+    def reduce(self):
+        """Enqueue the all-reduce after the work already on the current stream; later work on that stream
+        waits for it (stream order, the host does not block)."""
+        for c in self.chunks:
+            if self.backend_has_avg:
+                dist.all_reduce(c, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+                c.div_(self.world)
+
+    finish = reduce  # the name TrainStep's eager path calls
 
     def zero_grad(self):
         self.flat.grads.zero_()

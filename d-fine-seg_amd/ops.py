@@ -372,9 +372,9 @@ class _BatchNormAct(torch.autograd.Function):
                 _lib.ptr(lb32), n_pix, C, _ACT_CODES[act], int(training), eps, momentum)
         rc = 0
         if training:
-            with _lib.timed("bn_stats", xl.numel() * es):
+            with _lib.timed("bn_stats", xl.numel() * es, f"{n_pix}x{C}"):
                 rc = lib.dfine_bn_act_fwd(*args, 1, _lib.stream_ptr())
-        with _lib.timed("bn_apply", (xl.numel() + y.numel() + (al.numel() if al is not None else 0)) * es):
+        with _lib.timed("bn_apply", (xl.numel() + y.numel() + (al.numel() if al is not None else 0)) * es, f"{n_pix}x{C}"):
             rc = rc or lib.dfine_bn_act_fwd(*args, 2, _lib.stream_ptr())
         _lib.check(rc, "dfine_bn_act_fwd")
         ctx.save_for_backward(xl, al, g32, b32, save_mean, save_rstd, ls32)
@@ -411,9 +411,9 @@ class _BatchNormAct(torch.autograd.Function):
                 _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(ls32), _lib.ptr(red), _lib.ptr(dx), _lib.ptr(dadd), _lib.ptr(dgamma),
                 _lib.ptr(dbeta), _lib.ptr(dls) if ls32 is not None else None, _lib.ptr(dlb) if ls32 is not None else None,
                 n_pix, C, _ACT_CODES[act], training, eps)
-        with _lib.timed("bn_bwd_reduce", (xl.numel() + gy.numel() + n_add) * es):
+        with _lib.timed("bn_bwd_reduce", (xl.numel() + gy.numel() + n_add) * es, f"{n_pix}x{C}"):
             rc = lib.dfine_bn_act_bwd(*args, 1, _lib.stream_ptr())
-        with _lib.timed("bn_bwd_dx", (xl.numel() + 2 * gy.numel() + 2 * n_add) * es):
+        with _lib.timed("bn_bwd_dx", (xl.numel() + 2 * gy.numel() + 2 * n_add) * es, f"{n_pix}x{C}"):
             rc = rc or lib.dfine_bn_act_bwd(*args, 2, _lib.stream_ptr())
         _lib.check(rc, "dfine_bn_act_bwd")
         if direct:
@@ -660,12 +660,11 @@ class _Linear(torch.autograd.Function):
 def linear(x, weight, bias=None, row_begin=0, row_end=None):
     """``F.linear(x, weight[row_begin:row_end], bias[row_begin:row_end])``. On the GPU in bf16 mode
     (autocast, or bf16 input) the forward and the input gradient are library GEMMs and the weight/bias
-    gradient is the split-M HIP kernel; otherwise (fp32 parity runs, shapes with N or K not a multiple
-    of 8) it is plain ``F.linear``."""
+    gradient is the split-M HIP kernel; otherwise (fp32 parity runs, odd N or K) it is plain ``F.linear``."""
     row_end = weight.shape[0] if row_end is None else row_end
     n, k = row_end - row_begin, weight.shape[1]
     bf16_mode = x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16)
-    if not bf16_mode or n % 8 or k % 8 or not (weight.requires_grad and torch.is_grad_enabled()):
+    if not bf16_mode or n % 2 or k % 2 or not (weight.requires_grad and torch.is_grad_enabled()):
         w = weight if (row_begin == 0 and row_end == weight.shape[0]) else weight[row_begin:row_end]
         b = bias if (bias is None or (row_begin == 0 and row_end == weight.shape[0])) else bias[row_begin:row_end]
         return torch.nn.functional.linear(x, w, b)
@@ -732,7 +731,7 @@ def dense_conv(x, weight, stride=1, padding=0):
     MIOpen fp32 workspace, cast and accumulate launches); otherwise this is plain ``F.conv2d``."""
     k_out, c_in = weight.shape[0], weight.shape[1]
     bf16_mode = x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16)
-    if not bf16_mode or k_out % 8 or c_in % 8 or not (weight.requires_grad and torch.is_grad_enabled()):
+    if not bf16_mode or k_out % 2 or c_in % 8 or not (weight.requires_grad and torch.is_grad_enabled()):
         return torch.nn.functional.conv2d(x, weight, None, stride, padding)
     return _DenseConv.apply(x, weight, int(stride), int(padding))
 

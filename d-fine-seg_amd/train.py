@@ -61,6 +61,18 @@ class ModelEMA:
             self._ema_flat.mul_(decay_tensor).addcmul_(self._cur_flat, 1.0 - decay_tensor)
 
 
+class _SplitGraph:
+    """forward/backward graph -> gradient all-reduce -> optimizer graph, replayed as one step."""
+
+    def __init__(self, head, reducer, tail):
+        self.head, self.reducer, self.tail = head, reducer, tail
+
+    def replay(self):
+        self.head.replay()
+        self.reducer.reduce()
+        self.tail.replay()
+
+
 class TrainStep:
     """model + criterion + fused optimizer + OneCycle schedule + EMA; ``step(images, targets)`` runs
     one iteration and returns the (device-resident) total loss."""
@@ -90,7 +102,8 @@ class TrainStep:
         if self.grad_reducer is not None:  # non-trainable state is not in the flat buffer: align it once
             for t in list(self.model.buffers()) + [p for p in self.model.parameters() if not p.requires_grad]:
                 torch.distributed.broadcast(t, src=0)
-        self.use_graph = use_graph and self.device.type == "cuda" and self.grad_reducer is None
+        self.use_graph = (use_graph and self.device.type == "cuda"
+                          and (self.grad_reducer is None or getattr(self.grad_reducer, "graph_safe", False)))
         self.graph_warmup = graph_warmup
         self._graphs = {}  # (batch, max_gt, has_gt) -> (graph, static images, static TargetBatch, static loss)
         self._conv_norms = [m for m in self.model.modules() if isinstance(m, ConvNorm)]
@@ -101,7 +114,7 @@ class TrainStep:
         self.model.train()
 
     # ------------------------------------------------------------------ one step, device side
-    def _body(self, images, tb):
+    def _forward_backward(self, images, tb):
         from . import ops
 
         if ops.zero_arena is not None:
@@ -111,12 +124,19 @@ class TrainStep:
         losses = self.criterion(out)  # fp32, outside autocast like train.py:548-549
         loss = torch.stack(list(losses.values())).sum()  # one reduction instead of a chain of ~50 adds
         loss.backward()
-        if self.grad_reducer is not None:
-            self.grad_reducer.finish()
-        self.optimizer.launch()  # clip + AdamW + EMA(params) + zero grads
+        return loss.detach()
+
+    def _optimizer_tail(self):
+        self.optimizer.launch()  # clip + AdamW + EMA(params) + bf16 shadow + zero grads
         if self.ema is not None:
             self.ema.update_buffers(self.optimizer.hyper[6])
-        return loss.detach()
+
+    def _body(self, images, tb):
+        loss = self._forward_backward(images, tb)
+        if self.grad_reducer is not None:
+            self.grad_reducer.finish()
+        self._optimizer_tail()
+        return loss
 
     def _schedule(self):
         lrs = {g: one_cycle_lr(self.iters, self.total_steps, m, self.pct_start) for g, m in self.max_lrs.items()}
@@ -155,6 +175,14 @@ class TrainStep:
         s_images = images.clone()
         s_tb = TargetBatch(tb.labels.clone(), tb.boxes.clone(), tb.valid.clone(), list(tb.num_gts), tb.counts.clone(), None)
         graph = torch.cuda.CUDAGraph()
+        if self.grad_reducer is None:
+            with torch.cuda.graph(graph):
+                s_loss = self._body(s_images, s_tb)
+            return graph, s_images, s_tb, s_loss
+        # data parallel: two graphs with the gradient all-reduce (not captured) between their replays
         with torch.cuda.graph(graph):
-            s_loss = self._body(s_images, s_tb)
-        return graph, s_images, s_tb, s_loss
+            s_loss = self._forward_backward(s_images, s_tb)
+        tail = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(tail, pool=graph.pool()):
+            self._optimizer_tail()
+        return _SplitGraph(graph, self.grad_reducer, tail), s_images, s_tb, s_loss

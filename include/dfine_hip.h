@@ -213,7 +213,7 @@ int dfine_criterion_head(const void* logits, int logits_dtype, const float* boxe
  *     dW[n][k] += sum_m dY[m][n] * X[m][k]          db[n] += sum_m dY[m][n]   (db may be NULL)
  *   dY [M, N] bf16, X [M, K] bf16 (row-major); dW f32 rows of length K with leading dimension ldw
  *   (>= K), db f32 [N]. Both are ACCUMULATED with float atomics: point them at the fp32 gradient
- *   buffer itself (or at zeroed scratch). Needs N % 8 == 0 and K % 8 == 0.
+ *   buffer itself (or at zeroed scratch). Needs N and K even (4-byte aligned rows).
  * ------------------------------------------------------------------------------------- */
 int dfine_linear_wgrad(const void* dY, const void* X, float* dW, float* db, int M, int N, int K, int ldw,
                        void* stream);
@@ -226,7 +226,7 @@ int dfine_linear_wgrad(const void* dY, const void* X, float* dW, float* db, int 
  *   dY [B, OH, OW, CO] bf16, X [B, H, W, CI] bf16 (NHWC memory); dW f32 [CO][KH][KW][CI] -- the memory
  *   order of a channels_last weight -- ACCUMULATED with float atomics (point it at the fp32 gradient
  *   or at zeroed scratch). OH/OW must equal (H + 2*pad - KH) / stride + 1 (resp. W, KW).
- *   Needs CI % 8 == 0 and CO % 8 == 0.
+ *   Needs CI % 8 == 0 and CO even.
  * ------------------------------------------------------------------------------------- */
 int dfine_conv_wgrad(const void* dY, const void* X, float* dW, int B, int H, int W, int CI, int OH, int OW,
                      int CO, int KH, int KW, int stride, int pad, void* stream);

@@ -10,7 +10,7 @@ import torch.multiprocessing as mp
 import torch.nn as nn
 
 import dfine_seg_amd  # noqa: F401
-from dfine_seg_amd.ddp import BucketedGradReducer, assign_buckets
+from dfine_seg_amd.ddp import BucketedGradReducer, FlatGradAllReduce, assign_buckets
 from dfine_seg_amd.optim import FlatState
 
 
@@ -81,6 +81,44 @@ def test_bucketed_reducer_world2_gloo():
         assert dict(result) == {0: "ok", 1: "ok"}
 
 
+def _flat_worker(rank, world, port, result):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)
+        model = Toy()
+        reducer = FlatGradAllReduce(model, num_chunks=2)
+        gathered = [torch.zeros_like(model.a.weight) for _ in range(world)]
+        dist.all_gather(gathered, model.a.weight.detach())
+        assert all(torch.equal(gathered[0], g) for g in gathered)  # broadcast from rank 0
+        assert len(reducer.chunks) == 2 and sum(c.numel() for c in reducer.chunks) == reducer.flat.numel
+        for step in range(2):
+            x = torch.randn(5, 8, generator=torch.Generator().manual_seed(step * 10 + rank))
+            model(x).pow(2).sum().backward()
+            expect = {}
+            for n, p in model.named_parameters():
+                if p.requires_grad:
+                    t = p.grad.clone()
+                    dist.all_reduce(t)
+                    expect[n] = t / world
+            reducer.reduce()
+            for n, p in model.named_parameters():
+                if p.requires_grad:
+                    torch.testing.assert_close(p.grad, expect[n], rtol=1e-6, atol=1e-7)
+            reducer.zero_grad()
+        result[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_allreduce_world2_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        result = mgr.dict()
+        mp.spawn(_flat_worker, args=(world, _free_port(), result), nprocs=world, join=True)
+        assert dict(result) == {0: "ok", 1: "ok"}
+
+
 def test_bucket_assignment_covers_every_trainable_parameter_once():
     model = Toy()
     buckets = assign_buckets(FlatState(model).entries, num_buckets=3, min_bucket_bytes=64)
@@ -137,3 +175,46 @@ def test_reducer_rccl_single_rank_train_step(hip_lib):
     script = _RCCL_SCRIPT.format(root=ROOT, port=str(_free_port()))
     proc = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0 and "RCCL_OK" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-4000:]
+
+
+_RCCL_GRAPH_SCRIPT = """
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+import dfine_seg_amd
+from dfine_seg_amd.ddp import FlatGradAllReduce
+from dfine_seg_amd.synth import synthetic_batch
+from dfine_seg_amd.train import TrainStep, _SplitGraph
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT={port!r}, RANK="0", WORLD_SIZE="1")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+images, targets = synthetic_batch(2, 320, 320, 80, 4, seed=1, device="cuda")
+losses = []
+for reducer in (None, FlatGradAllReduce):
+    torch.manual_seed(0)
+    trainer = TrainStep("n", 80, False, (320, 320), "cuda", grad_reducer=reducer, total_steps=100, graph_warmup=2)
+    out = []
+    for i in range(5):
+        torch.manual_seed(10 + i)
+        out.append(float(trainer.step(images, targets)))
+    losses.append(out)
+    assert len(trainer._graphs) == 1
+    assert isinstance(next(iter(trainer._graphs.values()))[0], _SplitGraph) == (reducer is not None)
+    assert float(trainer.flat.grads.abs().max()) == 0.0
+for a, b in zip(*losses):
+    assert abs(a - b) <= 2e-2 * abs(a), losses  # bf16 steps, atomics order: same trajectory within noise
+dist.destroy_process_group()
+print("RCCL_GRAPH_OK")
+"""
+
+
+@pytest.mark.gpu
+def test_flat_allreduce_between_captured_graphs_rccl_single_rank(hip_lib):
+    """bench.py's N>1 schedule on the one GPU of the test box (1-rank RCCL group): graph(forward+backward)
+    -> flat all-reduce -> graph(optimizer) must follow the same loss trajectory as the single-GPU graph."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    script = _RCCL_GRAPH_SCRIPT.format(root=ROOT, port=str(_free_port()))
+    proc = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0 and "RCCL_GRAPH_OK" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-4000:]

@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
                                    (268800, 256, 256), (12800, 256, 256), (1000, 8, 8), (33, 72, 136), (1, 64, 64),
                                    # every tile shape: 128x128, 128x64, 64x128 (and the fallback to smaller tiles)
                                    (40000, 128, 128), (40000, 384, 64), (40000, 64, 384), (300000, 128, 256),
-                                   (2000, 256, 256), (700, 136, 264)])
+                                   (2000, 256, 256), (700, 136, 264),
+                                   # N or K not a multiple of 8 (bbox heads 4 / 132 outputs, LQE's 20 inputs)
+                                   (15744, 132, 256), (15744, 4, 256), (15744, 64, 20), (5000, 2, 6), (999, 70, 30)])
 def test_linear_wgrad_matches_fp32_reference(hip_lib, M, N, K):
     from dfine_seg_amd import _lib
 
@@ -36,9 +38,9 @@ def test_linear_wgrad_matches_fp32_reference(hip_lib, M, N, K):
 def test_unsupported_shape_is_rejected(hip_lib):
     from dfine_seg_amd import _lib
 
-    t = torch.zeros(16, 12, device="cuda", dtype=torch.bfloat16)
-    out = torch.zeros(12, 12, device="cuda")
-    assert hip_lib.dfine_linear_wgrad(_lib.ptr(t), _lib.ptr(t), _lib.ptr(out), None, 16, 12, 12, 12, None) == -2
+    t = torch.zeros(16, 13, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros(13, 13, device="cuda")
+    assert hip_lib.dfine_linear_wgrad(_lib.ptr(t), _lib.ptr(t), _lib.ptr(out), None, 16, 13, 13, 13, None) == -2  # odd: rows not 4-byte aligned
 
 
 def test_ops_linear_matches_torch_autograd(hip_lib):
@@ -103,6 +105,7 @@ def test_pointwise_conv_matches_torch(hip_lib):
     (2, 20, 20, 256, 64, 1, 1, 0),   # 1x1 through the conv entry
     (1, 9, 9, 8, 8, 5, 1, 2),        # 5x5, tiny
     (2, 16, 16, 24, 40, 3, 1, 1),    # channel counts that are multiples of 8 only
+    (2, 33, 33, 24, 12, 2, 1, 0),    # stem2a: 12 output channels
 ])
 def test_conv_wgrad_matches_fp32_reference(hip_lib, B, H, W, CI, CO, k, stride, pad):
     import torch.nn.functional as F
