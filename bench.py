@@ -90,6 +90,27 @@ def cpu_baseline(model, args, num_classes=80):
                       f"({args.gts} GT/img) through oracle/ on the host CPU"}
 
 
+TIMER_TO_DEVICE_KERNEL = {
+    "bn_stats": "bn_stats_kernel", "bn_apply": "bn_apply_kernel", "bn_bwd_reduce": "bn_bwd_reduce_kernel",
+    "bn_bwd_dx": "bn_bwd_dx_kernel", "wgrad": "wgrad_kernel", "msda_fwd": "msda_fwd_kernel", "msda_bwd": "msda_bwd_kernel",
+    "dwconv_fwd": "dwconv_fwd_kernel", "dwconv_bwd_data": "dwconv_bwd_data_kernel", "dwconv_bwd_weight": "dwconv_bwd_weight_kernel",
+    "criterion_head": "criterion_head_kernel", "grad_sumsq": "grad_sumsq_kernel", "adamw_ema_step": "adamw_ema_kernel",
+    "fdr_head_fwd": "fdr_head_fwd_kernel", "fdr_head_bwd": "fdr_head_bwd_kernel", "stem_pool_fwd": "pool_fwd_kernel",
+    "stem_pool_bwd": "pool_bwd_kernel",
+}
+
+
+def load_pmc_traffic():
+    """Newest profiles/*pmc_traffic.json (written by tools/pmc_traffic.sh on the GPU box and committed)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*pmc_traffic.json")))
+    if not files:
+        return {}, None
+    with open(files[-1]) as f:
+        return json.load(f), "profiles/" + os.path.basename(files[-1])
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -172,10 +193,17 @@ def main():
             kernels[name] = {"launches": st["launches"], "avg_us": round(st["avg_us"], 2),
                              "algorithmic_bytes": int(st["avg_bytes"]), "achieved_GBs": round(gbs, 1),
                              "ms_per_step": round(st["total_ms"] / probe_steps, 3)}
+        # HBM-side bytes per launch from the committed PMC passes of this same workload (tools/pmc_traffic.sh:
+        # separate FETCH_SIZE and WRITE_SIZE runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950)
+        pmc, pmc_file = load_pmc_traffic()
+        for name, k in kernels.items():
+            dev = TIMER_TO_DEVICE_KERNEL.get(name.split(" ")[0])
+            k["traffic_bytes"] = pmc[dev]["traffic_bytes"] if dev in pmc else None
         # the hand-written kernel the step spends most time in (all of them are HBM/L2-bound)
         dominant = max(ksum, key=lambda n: ksum[n]["total_ms"])
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": kernels[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(kernels[dominant]["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(kernels[dominant]["achieved_GBs"] / HBM_PEAK_GBS, 4),
+                    "traffic": kernels[dominant]["traffic_bytes"], "traffic_source": pmc_file,
                     "timing": f"HIP events over {probe_steps} eager steps run right after the timed region "
                               "(the timed steps replay a hipGraph)" if graph_was_on else "HIP events over eager steps",
                     "kernels": kernels}
@@ -191,6 +219,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "loss": round(loss_value, 4),
             "hip_graph": bool(graph_was_on),
+            "peak_device_memory_GB": round(torch.cuda.max_memory_allocated(device) / 2**30, 2),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -645,7 +645,7 @@ class _Linear(torch.autograd.Function):
         else:
             dw = torch.zeros(N, K, dtype=torch.float32, device=x16.device)
             db = torch.zeros(N, dtype=torch.float32, device=x16.device) if bias is not None else None
-        with _lib.timed("linear_wgrad", (M * N + M * K) * 2 + N * K * 4, f"M{M} N{N} K{K}"):
+        with _lib.timed("wgrad", (M * N + M * K) * 2 + N * K * 4, f"linear M{M} N{N} K{K}"):
             rc = lib.dfine_linear_wgrad(_lib.ptr(gy16), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), M, N, K, K, _lib.stream_ptr())
         _lib.check(rc, "dfine_linear_wgrad")
         if direct:
@@ -710,8 +710,8 @@ class _DenseConv(torch.autograd.Function):
         else:
             dw = torch.zeros(K_out, C_in, KH, KW, dtype=torch.float32, device=xl.device).contiguous(memory_format=torch.channels_last)
         M = B * OH * OW
-        with _lib.timed("conv1x1_wgrad" if taps == 1 else "conv_wgrad", (M * K_out + xl.numel()) * 2 + K_out * C_in * taps * 4,
-                        f"{B}x{H}x{W} {C_in}->{K_out} k{KH}s{stride}"):
+        with _lib.timed("wgrad", (M * K_out + xl.numel()) * 2 + K_out * C_in * taps * 4,
+                        f"conv {B}x{H}x{W} {C_in}->{K_out} k{KH}s{stride}"):
             rc = lib.dfine_conv_wgrad(_lib.ptr(gyl), _lib.ptr(xl), _lib.ptr(dw), B, H, W, C_in, OH, OW, K_out, KH, KW,
                                       stride, padding, _lib.stream_ptr())
         _lib.check(rc, "dfine_conv_wgrad")
