@@ -147,30 +147,36 @@ class DFINECriterion(nn.Module):
             losses["loss_ddf"] = (pos * cache["num_pos"] + neg * cache["num_neg"]) / (cache["num_pos"] + cache["num_neg"])
         return losses
 
-    def loss_masks(self, out, pairs, tb: TargetBatch, cache):
-        """Focal-BCE + dice on the matched queries only, dfine_criterion.py:272-357.
-        pairs = (image idx, query idx, gt idx) int64 [M] each."""
-        if "pred_masks" not in out:
+    def loss_masks(self, out, slots, tb: TargetBatch, cache):
+        """Focal-BCE + dice on the matched queries only, dfine_criterion.py:272-357, dense: ``slots`` =
+        (query index [B, M] int64, valid [B, M] bool, groups): target slot m of image b is ground truth
+        ``m % G`` (M = groups * G) and is predicted by query ``q[b, m]``. The logits are formed here, for the
+        matched rows only, from the head's mask embeddings and the shared feature map."""
+        if "pred_mask_embed" not in out:
             return {}
-        pm = out["pred_masks"]
-        Hm, Wm = pm.shape[-2:]
-        b, q, g = pairs
-        if b.numel() == 0 or tb.masks is None:
-            z = pm.sum() * 0
-            return {"loss_mask_bce": z, "loss_mask_dice": z}
+        embed, feat = out["pred_mask_embed"], cache["mask_feat"]
+        q, valid, groups = slots
+        B, M = q.shape
+        Hm, Wm = feat.shape[-2:]
         if "mask_targets" not in cache:
-            cache["mask_targets"] = tb.mask_targets(Hm, Wm, pm.device)[0]
-        pred = pm[b, q].float()
-        tgt = cache["mask_targets"][b, g]
-        fg = tgt.flatten(1).mean(1).view(-1, 1, 1)
-        alpha = 0.5 + 0.25 * (1 - 2 * fg).clamp(-1, 1)
+            cache["mask_targets"] = tb.dense_mask_targets(Hm, Wm, feat.device)  # [B, G, Hm, Wm] fp32
+            cache["mask_fg"] = cache["mask_targets"].flatten(2).mean(2)  # [B, G]
+        tgt, fg = cache["mask_targets"], cache["mask_fg"]
+        G = tgt.shape[1]
+        rows = embed.gather(1, q.unsqueeze(-1).expand(-1, -1, embed.shape[-1]))  # [B, M, C]
+        pred = torch.einsum("bmc,bchw->bmhw", rows.to(feat.dtype), feat).float().view(B, groups, G, Hm, Wm)
+        tgt = tgt.unsqueeze(1)  # broadcast over the denoising groups
+        alpha = (0.5 + 0.25 * (1 - 2 * fg).clamp(-1, 1)).view(B, 1, G, 1, 1)
         p = torch.sigmoid(pred)
-        bce = F.binary_cross_entropy_with_logits(pred, tgt, reduction="none")
+        bce = F.binary_cross_entropy_with_logits(pred, tgt.expand_as(pred), reduction="none")
         p_t = p * tgt + (1 - p) * (1 - tgt)
-        focal = ((alpha * tgt + (1 - alpha) * (1 - tgt)) * (1 - p_t) ** 2 * bce).mean((1, 2)).mean()
-        pf, tf = p.flatten(1), tgt.flatten(1)
-        dice = (1.0 - (2.0 * (pf * tf).sum(1) + 1e-6) / (pf.sum(1) + tf.sum(1) + 1e-6)).mean()
-        return {"loss_mask_bce": focal, "loss_mask_dice": dice}
+        focal = ((alpha * tgt + (1 - alpha) * (1 - tgt)) * (1 - p_t) ** 2 * bce).mean((3, 4))  # [B, groups, G]
+        inter, psum, tsum = (p * tgt).sum((3, 4)), p.sum((3, 4)), tgt.sum((3, 4))
+        dice = 1.0 - (2.0 * inter + 1e-6) / (psum + tsum + 1e-6)
+        w = valid.view(B, groups, G).float()
+        n = w.sum().clamp(min=1)  # mean over the matched pairs, like the reference's .mean() over gathered rows
+        zero_if_none = (w.sum() > 0).float()
+        return {"loss_mask_bce": (focal * w).sum() / n * zero_if_none, "loss_mask_dice": (dice * w).sum() / n * zero_if_none}
 
     # ------------------------------------------------------------------ forward
     @staticmethod
@@ -187,7 +193,7 @@ class DFINECriterion(nn.Module):
         if tb is None:
             tb = TargetBatch.from_list(targets, C, dev)
         aux, enc = outputs["aux_outputs"], outputs["enc_aux_outputs"]
-        main = {k: outputs[k] for k in ("pred_logits", "pred_boxes", "pred_corners", "ref_points", "pred_masks") if k in outputs}
+        main = {k: outputs[k] for k in ("pred_logits", "pred_boxes", "pred_corners", "ref_points", "pred_mask_embed") if k in outputs}
         heads = [main] + list(aux) + [outputs["pre_outputs"]] + list(enc)
         # ---- all matchings of the step at once (matcher.py:52-130 x (L+2))
         logits = torch.stack([h["pred_logits"].detach().float() for h in heads])
@@ -209,9 +215,8 @@ class DFINECriterion(nn.Module):
         if fdr is None:  # outputs not produced by this package's decoder: read the Parameters (one sync)
             fdr = {"W": weighting_function(spec.reg_max, outputs["up"], outputs["reg_scale"]).to(dev),
                    "reg_scale": float(outputs["reg_scale"].detach().abs().reshape(-1)[0])}
-        with_masks = "masks" in self.losses
-        pairs_bg = self._host_pairs(tb.num_gts, dev) if with_masks else None
-        cache, losses = {"fdr": fdr}, {}
+        with_masks = "masks" in self.losses and "mask_feat" in outputs and (tb.masks is not None or tb.mask_tgt is not None)
+        cache, losses = {"fdr": fdr, "mask_feat": outputs.get("mask_feat")}, {}
 
         # ---- denoising heads: deterministic matching (get_cdn_matched_indices, :610-632), dense
         has_dn = "dn_outputs" in outputs
@@ -223,20 +228,19 @@ class DFINECriterion(nn.Module):
             if dn_assign is None:
                 dn_assign = torch.full(outputs["dn_pre_outputs"]["pred_logits"].shape[:2], -1, dtype=torch.int64, device=dev)
             dn_pairs = None
-            if with_masks:
-                G = max(tb.num_gts) if tb.total else 1
-                b, g = pairs_bg
-                reps = torch.arange(max(groups, 0), device=dev)
-                dn_pairs = (b.repeat(max(groups, 0)), (reps[:, None] * 2 * G + g[None, :]).flatten(), g.repeat(max(groups, 0)))
+            if with_masks and groups > 0:
+                # positive slot of ground truth g in group k is denoising query k*2G + g (G = padded GT width)
+                G = tb.max_gt
+                q_dn = (torch.arange(groups, device=dev)[:, None] * 2 * G + torch.arange(G, device=dev)[None, :]).flatten()
+                dn_pairs = (q_dn[None, :].expand(tb.valid.shape[0], -1), tb.valid.repeat(1, groups), groups)
 
         def own_pairs(h):
             if not with_masks:
                 return None
-            b, g = pairs_bg
-            return b, query_of_gt[h].long()[b, g], g
+            return query_of_gt[h].long().clamp(min=0), tb.valid, 1
 
         def mask_terms(out, pairs, suffix):
-            if with_masks:
+            if with_masks and pairs is not None:
                 res = self.loss_masks(out, pairs, tb, cache)
                 losses.update({k + suffix: v * self.weight_dict[k] for k, v in res.items() if k in self.weight_dict})
 
@@ -260,8 +264,8 @@ class DFINECriterion(nn.Module):
             for i, out in enumerate(outputs["dn_outputs"]):
                 head(out, f"_dn_{i}", None, local=True, dn=(dn_assign, dn_nb))
                 mask_terms(out, dn_pairs, f"_dn_{i}")
-            if "dn_pred_masks" in outputs and with_masks:
-                mask_terms({"pred_masks": outputs["dn_pred_masks"]}, dn_pairs, "_dn_final")
+            if "dn_pred_mask_embed" in outputs and with_masks:
+                mask_terms({"pred_mask_embed": outputs["dn_pred_mask_embed"]}, dn_pairs, "_dn_final")
             head(outputs["dn_pre_outputs"], "_dn_pre", None, local=True, dn=(dn_assign, dn_nb))
             mask_terms(outputs["dn_pre_outputs"], dn_pairs, "_dn_pre")
         return {k: torch.nan_to_num(v, nan=0.0) for k, v in losses.items()}

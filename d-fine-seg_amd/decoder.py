@@ -49,6 +49,12 @@ def distance2bbox(points, distance, reg_scale):
     return torch.stack([(x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1], -1)
 
 
+def mask_logits(embed, mask_feat):
+    """Mask logits of queries: embed [B, Q, C] x mask_feat [B, C, H, W] -> [B, Q, H, W]
+    (``_mask_logits_from_h``, dfine_decoder.py:937-940)."""
+    return torch.einsum("bqc,bchw->bqhw", embed.to(mask_feat.dtype), mask_feat)
+
+
 class MSDeformableAttention(nn.Module):
     """Offsets and weights from the query, locations around the 4-d reference box
     (dfine_decoder.py:148-166), then the HIP gather. No value/output projection."""
@@ -305,7 +311,7 @@ class DFINETransformer(nn.Module):
         tb = None
         if targets is not None:
             tb = TargetBatch.from_list(targets, self.num_classes, dev)
-        do_masks = self.enable_mask_head and (tb is None or tb.masks is not None)
+        do_masks = self.enable_mask_head and (tb is None or tb.masks is not None or tb.mask_tgt is not None)
 
         dn_content = dn_bbox = blocked = dn_meta = None
         if training:
@@ -366,7 +372,7 @@ class DFINETransformer(nn.Module):
             h8, w8 = spatial_shapes[0]
             mem0 = memory[:, : h8 * w8].transpose(1, 2).reshape(B, hid, h8, w8)
             mask_feat = self.pixel_decoder(inner_feats, mem0)
-            mask_of = lambda h: torch.einsum("bqc,bchw->bqhw", self.mask_head(h), mask_feat)
+            mask_of = lambda h: mask_logits(self.mask_head(h), mask_feat)
 
         if not training:
             res = {"pred_logits": logits_l[-1], "pred_boxes": boxes_l[-1]}
@@ -385,26 +391,32 @@ class DFINETransformer(nn.Module):
             if teacher and i == L - 1:
                 d["self_distilled"] = True  # teacher == student: the reference finds out with torch.equal (a sync)
             if masks is not None:
-                d["pred_masks"] = masks[i]
+                d["pred_mask_embed"] = masks[i]
             return d
 
-        reg_masks = [mask_of(reg_part(h)) for h in hs] if do_masks else None
+        # Mask logits are NOT materialised for every query (the reference's einsum writes 4 x [B,492,160,160]
+        # and the loss then reads the matched rows only, dfine_decoder.py:999-1022): heads carry the mask
+        # embeddings [B, Lq, hidden] and the shared feature map; the criterion forms the logits of the
+        # matched rows after matching. ``mask_logits(embed, feat)`` gives the reference's tensor on demand.
+        embeds = [self.mask_head(h) for h in hs] if do_masks else None
+        reg_masks = [reg_part(e) for e in embeds] if do_masks else None
         res = {k: v for k, v in head(reg_part, L - 1, False).items() if v is not None}
         res.update(up=self.up, reg_scale=self.reg_scale)
         res["fdr"] = {"W": project, "reg_scale": reg_scale}  # host-side copies so the criterion need not read the Parameters back
         if do_masks:
-            res["pred_masks"] = reg_masks[-1]
+            res["pred_mask_embed"] = reg_masks[-1]
+            res["mask_feat"] = mask_feat
         res["aux_outputs"] = [head(reg_part, i, True, reg_masks) for i in range(L - 1)]
         res["enc_aux_outputs"] = [{"pred_logits": topk_logits, "pred_boxes": torch.sigmoid(enc_bbox_unact)}]
         res["pre_outputs"] = {"pred_logits": reg_part(pre_logits), "pred_boxes": reg_part(pre_boxes)}
         res["enc_meta"] = {"class_agnostic": False}
-        dn_masks = [mask_of(dn_part(h)) for h in hs] if do_masks else None
+        dn_masks = [dn_part(e) for e in embeds] if do_masks else None
         # detection: every layer's dn head; with masks the reference's zip truncates to L-1 layers and
         # carries the last layer's dn masks separately (:1059-1070)
         n_dn = L - 1 if do_masks else L
         res["dn_outputs"] = [head(dn_part, i, True, dn_masks) for i in range(n_dn)]
         if dn_masks is not None:
-            res["dn_pred_masks"] = dn_masks[-1]
+            res["dn_pred_mask_embed"] = dn_masks[-1]
         res["dn_pre_outputs"] = {"pred_logits": dn_part(pre_logits), "pred_boxes": dn_part(pre_boxes)}
         res["dn_meta"] = dn_meta
         res["targets"] = tb  # the packed batch, so the criterion does not pack it again

@@ -21,6 +21,7 @@ class TargetBatch:
     num_gts: List[int]  # host
     counts: torch.Tensor = None  # int32 [B] on the device (same numbers as num_gts)
     masks: Optional[List[Optional[torch.Tensor]]] = None  # per image uint8 [n, H, W] (segment task)
+    mask_tgt: Optional[torch.Tensor] = None  # f32 [B, G, Hm, Wm]: masks resized to the prediction size, see dense_mask_targets
 
     @property
     def max_gt(self):
@@ -63,6 +64,13 @@ class TargetBatch:
         if any(t.get("masks") is not None and t["masks"].numel() > 0 for t in targets):
             masks = [t.get("masks") for t in targets]
         return TargetBatch(labels, boxes, valid, num_gts, counts.to(torch.int32).to(device, non_blocking=True), masks)
+
+    def dense_mask_targets(self, out_h, out_w, device):
+        """[B, G, out_h, out_w] fp32 targets, computed once per batch (``mask_tgt``); a captured step is
+        handed the tensor ready-made (train.TrainStep) so the per-image resize stays outside the graph."""
+        if self.mask_tgt is None or tuple(self.mask_tgt.shape[-2:]) != (out_h, out_w):
+            self.mask_tgt = self.mask_targets(out_h, out_w, device)[0]
+        return self.mask_tgt
 
     def mask_targets(self, out_h, out_w, device):
         """GT masks nearest-resized to the prediction size (dfine_criterion.py:239-270), padded to

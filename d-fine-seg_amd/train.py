@@ -80,7 +80,7 @@ class TrainStep:
     def __init__(self, model_name="m", num_classes=80, enable_mask_head=False, img_size=(640, 640),
                  device="cuda", base_lr=1.5e-4, backbone_lr=2e-5, betas=(0.9, 0.999), weight_decay=1.25e-4,
                  clip_max_norm=0.1, use_ema=True, ema_momentum=0.9998, amp=True, total_steps=10000,
-                 pct_start=0.1, grad_reducer=None, use_graph=True, graph_warmup=3):
+                 pct_start=0.1, grad_reducer=None, use_graph=True, graph_warmup=3, graph_masks=False):
         self.device = torch.device(device)
         self.num_classes = num_classes
         self.model = build_model(model_name, num_classes, enable_mask_head, self.device, img_size=list(img_size))
@@ -105,6 +105,7 @@ class TrainStep:
         self.use_graph = (use_graph and self.device.type == "cuda"
                           and (self.grad_reducer is None or getattr(self.grad_reducer, "graph_safe", False)))
         self.graph_warmup = graph_warmup
+        self.graph_masks = graph_masks
         self._graphs = {}  # (batch, max_gt, has_gt) -> (graph, static images, static TargetBatch, static loss)
         self._conv_norms = [m for m in self.model.modules() if isinstance(m, ConvNorm)]
         if self.device.type == "cuda":  # zero-initialised scratch for the fused ops: one memset per step
@@ -151,9 +152,14 @@ class TrainStep:
         self._schedule()
         if not self.flat.bf16_shadow_is_current():  # weights were written behind the optimizer's back (load_state_dict, ...)
             self.flat.refresh_bf16_shadow()
-        if not self.use_graph or tb.masks is not None or self.iters <= self.graph_warmup:
+        if tb.masks is not None:  # per-image resize of the GT masks to the mask-logit size: host loop, outside any capture
+            tb.dense_mask_targets(images.shape[-2] // 4, images.shape[-1] // 4, self.device)
+        # segment task: the step with the mask branch is capturable by construction (dense, sync-free), but
+        # the one captured segment run of round 1 ended in a GPU memory fault that is not yet explained, so
+        # mask batches run eagerly unless ``graph_masks`` is set
+        if not self.use_graph or self.iters <= self.graph_warmup or (tb.mask_tgt is not None and not self.graph_masks):
             return self._body(images, tb)
-        key = (tuple(images.shape), tb.max_gt, max(tb.num_gts), tb.total > 0)
+        key = (tuple(images.shape), tb.max_gt, max(tb.num_gts), tb.total > 0, tb.mask_tgt is not None)
         entry = self._graphs.get(key)
         if entry is None:
             entry = self._graphs[key] = self._capture(images, tb)
@@ -163,6 +169,8 @@ class TrainStep:
         s_tb.boxes.copy_(tb.boxes, non_blocking=True)
         s_tb.valid.copy_(tb.valid, non_blocking=True)
         s_tb.counts.copy_(tb.counts, non_blocking=True)
+        if s_tb.mask_tgt is not None:
+            s_tb.mask_tgt.copy_(tb.mask_tgt, non_blocking=True)
         graph.replay()
         for m in self._conv_norms:  # host-side batch counters the replay does not run
             m._pending_batches += 1
@@ -173,7 +181,8 @@ class TrainStep:
         counts inside may vary between replays; the maximum (it fixes the number of denoising
         queries) may not -- a new maximum gets its own graph."""
         s_images = images.clone()
-        s_tb = TargetBatch(tb.labels.clone(), tb.boxes.clone(), tb.valid.clone(), list(tb.num_gts), tb.counts.clone(), None)
+        s_tb = TargetBatch(tb.labels.clone(), tb.boxes.clone(), tb.valid.clone(), list(tb.num_gts), tb.counts.clone(), None,
+                           tb.mask_tgt.clone() if tb.mask_tgt is not None else None)
         graph = torch.cuda.CUDAGraph()
         if self.grad_reducer is None:
             with torch.cuda.graph(graph):
