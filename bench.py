@@ -43,6 +43,7 @@ def parse():
                     help="N>1: eager step + bucketed all-reduce overlapped with backward (default: captured graphs + one flat all-reduce)")
     ap.add_argument("--force-ddp", action="store_true",
                     help="diagnostic: take the N>1 code path (process group, reducer, split graphs) even with one rank")
+    ap.add_argument("--graph-masks", action="store_true", help="segment task: capture the step with the mask branch too (default: eager)")
     ap.add_argument("--shapes", action="store_true", help="diagnostic: key the per-kernel timings by operand shape")
     return ap.parse_args()
 
@@ -146,7 +147,7 @@ def main():
     torch.backends.cudnn.benchmark = not args.no_miopen_find
     torch.manual_seed(42 + rank)  # per-rank seed like train.py:131
     trainer = TrainStep(args.model, 80, seg, (args.img, args.img), device, total_steps=max(1000, args.steps + args.warmup + 1),
-                        grad_reducer=reducer, use_graph=not args.no_graph)
+                        grad_reducer=reducer, use_graph=not args.no_graph, graph_masks=args.graph_masks)
     images, targets = synthetic_batch(args.batch, args.img, args.img, 80, args.gts, with_masks=seg, seed=42 + rank, device=device)
     images = images.contiguous(memory_format=torch.channels_last)
 

@@ -32,10 +32,12 @@ class ZeroArena:
         self.high_water = 0
 
     def reset(self):
-        """Zero what the previous step touched and start handing out from the beginning."""
-        if self.used:
-            self.buf[: self.used].zero_()
+        """Zero everything any earlier step touched and start handing out from the beginning. (Not just
+        the previous step's extent: inside a captured graph the memset length is frozen at capture time,
+        and steps of different kinds -- eager/captured, with/without masks -- use different amounts.)"""
         self.high_water = max(self.high_water, self.used)
+        if self.high_water:
+            self.buf[: self.high_water].zero_()
         self.used = 0
 
     def take(self, n):

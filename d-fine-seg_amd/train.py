@@ -153,10 +153,12 @@ class TrainStep:
         if not self.flat.bf16_shadow_is_current():  # weights were written behind the optimizer's back (load_state_dict, ...)
             self.flat.refresh_bf16_shadow()
         if tb.masks is not None:  # per-image resize of the GT masks to the mask-logit size: host loop, outside any capture
-            tb.dense_mask_targets(images.shape[-2] // 4, images.shape[-1] // 4, self.device)
-        # segment task: the step with the mask branch is capturable by construction (dense, sync-free), but
-        # the one captured segment run of round 1 ended in a GPU memory fault that is not yet explained, so
-        # mask batches run eagerly unless ``graph_masks`` is set
+            s = self.model.decoder.spec.strides[0] // 2  # mask logits live at half the finest stride (ConvTranspose 2x2)
+            tb.dense_mask_targets(images.shape[-2] // s, images.shape[-1] // s, self.device)
+        # segment task: the step with the mask branch is capturable by construction (dense, sync-free) and the
+        # captured D-FINE-n step replays to the eager losses (tests/test_optim.py), but both captured runs of
+        # D-FINE-m at batch 32 ended in a GPU memory-aperture fault after a few replays while the eager step
+        # with the same kernels is clean -- unexplained, so mask batches run eagerly unless ``graph_masks``
         if not self.use_graph or self.iters <= self.graph_warmup or (tb.mask_tgt is not None and not self.graph_masks):
             return self._body(images, tb)
         key = (tuple(images.shape), tb.max_gt, max(tb.num_gts), tb.total > 0, tb.mask_tgt is not None)

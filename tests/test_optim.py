@@ -149,3 +149,26 @@ def test_bf16_shadow_follows_the_master_weights(hip_lib):
     flat.refresh_bf16_shadow()
     assert flat.bf16_shadow_is_current() and ops.bf16_of(w).data_ptr() == w._bf16_shadow.data_ptr()
     assert torch.equal(flat.shadow, flat.params.to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+def test_graph_replay_matches_eager_segment(hip_lib):
+    """Same as above with the mask branch in the captured step (graph_masks=True): pixel decoder, mask
+    embeddings, matched-rows mask logits and the dense focal/dice loss must replay to the eager losses."""
+    from dfine_seg_amd.synth import synthetic_batch
+    from dfine_seg_amd.train import TrainStep
+
+    losses = {}
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        t = TrainStep("n", 80, True, (320, 320), "cuda", total_steps=100, use_graph=use_graph, graph_warmup=2, amp=False,
+                      graph_masks=True)
+        out = []
+        for i in range(5):
+            torch.manual_seed(100 + i)
+            images, targets = synthetic_batch(2, 320, 320, 80, 4, with_masks=True, seed=i, device="cuda")
+            out.append(float(t.step(images, targets)))
+        losses[use_graph] = out
+        assert (len(t._graphs) == 1) == use_graph
+    for a, b in zip(losses[False], losses[True]):
+        assert abs(a - b) <= 2e-3 * abs(a), (losses[False], losses[True])
