@@ -164,14 +164,23 @@ class DFINECriterion(nn.Module):
         tgt, fg = cache["mask_targets"], cache["mask_fg"]
         G = tgt.shape[1]
         rows = embed.gather(1, q.unsqueeze(-1).expand(-1, -1, embed.shape[-1]))  # [B, M, C]
-        pred = torch.einsum("bmc,bchw->bmhw", rows.to(feat.dtype), feat).float().view(B, groups, G, Hm, Wm)
-        tgt = tgt.unsqueeze(1)  # broadcast over the denoising groups
-        alpha = (0.5 + 0.25 * (1 - 2 * fg).clamp(-1, 1)).view(B, 1, G, 1, 1)
-        p = torch.sigmoid(pred)
-        bce = F.binary_cross_entropy_with_logits(pred, tgt.expand_as(pred), reduction="none")
-        p_t = p * tgt + (1 - p) * (1 - tgt)
-        focal = ((alpha * tgt + (1 - alpha) * (1 - tgt)) * (1 - p_t) ** 2 * bce).mean((3, 4))  # [B, groups, G]
-        inter, psum, tsum = (p * tgt).sum((3, 4)), p.sum((3, 4)), tgt.sum((3, 4))
+        pred = torch.einsum("bmc,bchw->bmhw", rows.to(feat.dtype), feat)  # [B, M, Hm, Wm], M = groups * G
+        alpha = 0.5 + 0.25 * (1 - 2 * fg).clamp(-1, 1)  # [B, G]
+        if self.fused and pred.is_cuda and (Hm * Wm) % 8 == 0 and B * M <= 65535:
+            # HIP: per-row sums of the focal terms, p*t and p in one pass (and one pass backward)
+            stats = ops.mask_row_stats(pred.reshape(B, M, Hm * Wm), tgt.reshape(B, G, Hm * Wm), alpha).view(B, groups, G, 3)
+            focal = stats[..., 0] / float(Hm * Wm)
+            inter, psum = stats[..., 1], stats[..., 2]
+            tsum = (fg * float(Hm * Wm)).unsqueeze(1)
+        else:
+            pred = pred.float().view(B, groups, G, Hm, Wm)
+            tgt5 = tgt.unsqueeze(1)  # broadcast over the denoising groups
+            a5 = alpha.view(B, 1, G, 1, 1)
+            p = torch.sigmoid(pred)
+            bce = F.binary_cross_entropy_with_logits(pred, tgt5.expand_as(pred), reduction="none")
+            p_t = p * tgt5 + (1 - p) * (1 - tgt5)
+            focal = ((a5 * tgt5 + (1 - a5) * (1 - tgt5)) * (1 - p_t) ** 2 * bce).mean((3, 4))  # [B, groups, G]
+            inter, psum, tsum = (p * tgt5).sum((3, 4)), p.sum((3, 4)), tgt5.sum((3, 4))
         dice = 1.0 - (2.0 * inter + 1e-6) / (psum + tsum + 1e-6)
         w = valid.view(B, groups, G).float()
         n = w.sum().clamp(min=1)  # mean over the matched pairs, like the reference's .mean() over gathered rows

@@ -544,6 +544,46 @@ def stem_pool_supported(x):
     return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0
 
 
+class _MaskRowStats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, tgt, alpha):
+        _lib.require_gpu(logits, tgt, alpha)
+        lib = _lib.load()
+        B, M, HW = logits.shape
+        G = tgt.shape[1]
+        z = logits.contiguous()
+        t = tgt.float().contiguous()
+        a = alpha.float().contiguous()
+        stats = torch.empty(B, M, 3, dtype=torch.float32, device=z.device)
+        with _lib.timed("mask_loss_stats", z.numel() * z.element_size() + t.numel() * 4 * (M // G)):
+            rc = lib.dfine_mask_loss_stats(_lib.ptr(z), _lib.dtype_code(z), _lib.ptr(t), _lib.ptr(a), _lib.ptr(stats),
+                                           B, M, G, HW, _lib.stream_ptr())
+        _lib.check(rc, "dfine_mask_loss_stats")
+        ctx.save_for_backward(z, t, a)
+        return stats
+
+    @staticmethod
+    def backward(ctx, g_stats):
+        z, t, a = ctx.saved_tensors
+        lib = _lib.load()
+        B, M, HW = z.shape
+        G = t.shape[1]
+        g = g_stats.float().contiguous()
+        dz = torch.empty_like(z)
+        with _lib.timed("mask_loss_grad", 2 * z.numel() * z.element_size() + t.numel() * 4 * (M // G)):
+            rc = lib.dfine_mask_loss_grad(_lib.ptr(z), _lib.dtype_code(z), _lib.ptr(t), _lib.ptr(a), _lib.ptr(g), _lib.ptr(dz),
+                                          B, M, G, HW, _lib.stream_ptr())
+        _lib.check(rc, "dfine_mask_loss_grad")
+        return dz, None, None
+
+
+def mask_row_stats(logits, tgt, alpha):
+    """logits [B, M, HW] (f32/bf16) of the matched queries, tgt [B, G, HW] in [0,1] (M a multiple of G:
+    slot m is ground truth m % G), alpha [B, G] -> stats [B, M, 3] fp32 = (sum of the focal-BCE terms,
+    sum p*t, sum p) per row, differentiable w.r.t. logits (dfine_criterion.py:272-357)."""
+    return _MaskRowStats.apply(logits, tgt, alpha)
+
+
 class _FdrHead(torch.autograd.Function):
     """softmax -> Integral -> distance2bbox and the LQE statistics in one launch (csrc/fdr.hip)."""
 
