@@ -19,10 +19,19 @@ struct MaskGeom {
   int M, G, HW;
 };
 
+// sigmoid and softplus from ONE exponential: e = exp(-|z|), p = (z >= 0 ? 1 : e) / (1 + e), softplus = max(z, 0) + log(1 + e)
+__device__ __forceinline__ void sigmoid_softplus(float z, float& p, float& softplus) {
+  const float e = __expf(-fabsf(z));
+  const float r = __frcp_rn(1.f + e);
+  p = z >= 0.f ? r : e * r;
+  softplus = fmaxf(z, 0.f) + __logf(1.f + e);
+}
+
 __device__ __forceinline__ void mask_terms(float z, float t, float alpha, float& focal, float& p_out) {
-  const float p = 1.f / (1.f + expf(-z));
-  const float bce = fmaxf(z, 0.f) - z * t + log1pf(expf(-fabsf(z)));  // softplus(z) - z t, stable
-  const float one_m_pt = p + t - 2.f * p * t;                          // 1 - p_t
+  float p, sp;
+  sigmoid_softplus(z, p, sp);
+  const float bce = sp - z * t;                 // softplus(z) - z t
+  const float one_m_pt = p + t - 2.f * p * t;   // 1 - p_t
   const float a_t = alpha * t + (1.f - alpha) * (1.f - t);
   focal = a_t * one_m_pt * one_m_pt * bce;
   p_out = p;
@@ -39,7 +48,9 @@ __global__ __launch_bounds__(256) void mask_stats_kernel(const T* __restrict__ l
   const float* t = tgt + ((size_t)b * g.G + gt) * g.HW;
   const float a = alpha[b * g.G + gt];
   float s_f = 0.f, s_i = 0.f, s_p = 0.f;
-  for (int i = threadIdx.x * V; i < g.HW; i += blockDim.x * V) {  // HW % V == 0 (checked on the host)
+  // a row is shared by gridDim.y workgroups (few rows -- the 8 ground truths of the own heads -- would
+  // otherwise leave most CUs idle); partial sums are added to the zero-initialised stats
+  for (int i = (blockIdx.y * blockDim.x + threadIdx.x) * V; i < g.HW; i += gridDim.y * blockDim.x * V) {  // HW % V == 0
     float zz[V], tt[V];
     load_vec<T, V>(z + i, zz);
 #pragma unroll
@@ -58,7 +69,8 @@ __global__ __launch_bounds__(256) void mask_stats_kernel(const T* __restrict__ l
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) red[wave][0] = s_f, red[wave][1] = s_i, red[wave][2] = s_p;
   __syncthreads();
-  if (threadIdx.x < 3) stats[(size_t)row * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (threadIdx.x < 3)
+    atomicAdd(stats + (size_t)row * 3 + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 template <typename T>
@@ -80,9 +92,10 @@ __global__ __launch_bounds__(256) void mask_grad_kernel(const T* __restrict__ lo
 #pragma unroll
   for (int k = 0; k < V; ++k) {
     const float z = zz[k], tk = tt[k];
-    const float p = 1.f / (1.f + expf(-z));
+    float p, sp;
+    sigmoid_softplus(z, p, sp);
     const float pq = p * (1.f - p);
-    const float bce = fmaxf(z, 0.f) - z * tk + log1pf(expf(-fabsf(z)));
+    const float bce = sp - z * tk;
     const float one_m_pt = p + tk - 2.f * p * tk;
     const float a_t = a * tk + (1.f - a) * (1.f - tk);
     // d(1 - p_t)/dz = (1 - 2t) p (1-p);  d bce/dz = p - t
@@ -101,7 +114,11 @@ static int launch_mask(bool fwd, const void* logits, const float* tgt, const flo
   const long long rows = (long long)B * M;
   if (rows > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
   if (fwd) {
-    hipLaunchKernelGGL(mask_stats_kernel<T>, dim3((unsigned)rows), dim3(256), 0, st, (const T*)logits, tgt, alpha, (float*)out, g);
+    int split = (int)((2048 + rows - 1) / rows);  // >= 2048 workgroups
+    const int max_split = (HW / V + 255) / 256;
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    hipLaunchKernelGGL(mask_stats_kernel<T>, dim3((unsigned)rows, split), dim3(256), 0, st, (const T*)logits, tgt, alpha, (float*)out, g);
   } else {
     if (rows > 65535) return DFINE_E_UNSUPPORTED;
     const int bx = (HW / V + 255) / 256;

@@ -554,7 +554,7 @@ class _MaskRowStats(torch.autograd.Function):
         z = logits.contiguous()
         t = tgt.float().contiguous()
         a = alpha.float().contiguous()
-        stats = torch.empty(B, M, 3, dtype=torch.float32, device=z.device)
+        stats = zeros_f32(B * M * 3, z.device).view(B, M, 3)
         with _lib.timed("mask_loss_stats", z.numel() * z.element_size() + t.numel() * 4 * (M // G)):
             rc = lib.dfine_mask_loss_stats(_lib.ptr(z), _lib.dtype_code(z), _lib.ptr(t), _lib.ptr(a), _lib.ptr(stats),
                                            B, M, G, HW, _lib.stream_ptr())

@@ -271,7 +271,7 @@ int dfine_stem_pool_bwd(const void* x, const void* gy, int dtype, void* gx, int 
  *     p = sigmoid(z), p_t = p t + (1-p)(1-t), a_t = alpha t + (1-alpha)(1-t), bce = softplus(z) - z t
  *     stats[b][m] = ( sum a_t (1-p_t)^2 bce ,  sum p t ,  sum p )            over the HW pixels
  *   logits [B, M, HW] f32 or bf16 (dtype), tgt f32 [B, G, HW] in [0,1], alpha f32 [B, G]
- *   (0.5 + 0.25 clamp(1 - 2 fg, -1, 1), fg = mean of t, :285-291), stats f32 [B, M, 3] (written).
+ *   (0.5 + 0.25 clamp(1 - 2 fg, -1, 1), fg = mean of t, :285-291), stats f32 [B, M, 3] (ACCUMULATED: zero it).
  * dfine_mask_loss_grad: g_stats f32 [B, M, 3] = d(loss)/d(stats)  ->  d_logits [B, M, HW] (logits' dtype,
  *   written). The means, the dice ratio and the average over matched pairs are the caller's.
  *   Needs HW % 8 == 0 (bf16) / HW % 4 == 0 (f32); grad: B*M <= 65535.

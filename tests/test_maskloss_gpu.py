@@ -37,7 +37,7 @@ def test_mask_row_stats_match_torch(hip_lib, dtype, B, G, groups, HW):
     (ref * gs).sum().backward()
     zd = z.detach().clone().requires_grad_(True)
     stats = ops.mask_row_stats(zd, t, alpha)
-    torch.testing.assert_close(stats, ref.detach(), rtol=2e-5, atol=2e-3)  # fp32 sums of HW terms, other order
+    torch.testing.assert_close(stats, ref.detach(), rtol=1e-4, atol=2e-3)  # fp32 sums of HW terms in another order, fast exp/log
     (stats * gs).sum().backward()
     assert zd.grad.dtype == dtype
     tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=2e-2)
