@@ -37,6 +37,8 @@ SIGNATURES = {
     "dfine_stem_pool_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p] + [_c_int] * 4 + [_c_void_p],
     "dfine_mask_loss_stats": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_int] * 4 + [_c_void_p],
     "dfine_mask_loss_grad": [_c_void_p, _c_int] + [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p],
+    "dfine_add_layernorm_fwd": [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 6 + [ctypes.c_longlong, _c_int, ctypes.c_float, ctypes.c_float, _c_void_p],
+    "dfine_add_layernorm_bwd": [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 6 + [ctypes.c_longlong, _c_int, ctypes.c_float, _c_void_p],
     "dfine_grad_sumsq": [_c_void_p, ctypes.c_longlong, _c_void_p, _c_void_p],
     "dfine_adamw_ema_step": [_c_void_p] * 8 + [ctypes.POINTER(ctypes.c_longlong), _c_int, ctypes.c_longlong, _c_void_p],
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],

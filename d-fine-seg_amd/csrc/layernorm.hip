@@ -1,0 +1,166 @@
+// Residual add + LayerNorm over the last dimension, forward and backward, in the activations' own dtype:
+//     s = clamp(x + res), y = (s - mean(s)) * rstd(s) * gamma + beta
+// (post-norm blocks of the decoder and the AIFI layer: reference src/d_fine/arch/dfine_decoder.py:233-255
+// `norm1(tgt + dropout(attn))`, `norm3(clamp(tgt + ffn))`, Gate :258-271; hybrid_encoder.py:274-290).
+// Under autocast the stock LayerNorm runs in fp32: a cast in, a cast out, three backward kernels and the
+// residual add are separate launches over [B*Lq, D]; here each direction is one launch and bf16 stays bf16.
+//
+// One wave per row (D = 64 * E elements, E in {2, 4, 8}: each lane owns E consecutive elements = one
+// 4/8/16-byte access for bf16), statistics by wave shuffles in fp32. Backward accumulates d gamma / d beta
+// per lane over the rows a wave walks, then one LDS reduction and float atomics per workgroup.
+#include "common.h"
+
+namespace dfine {
+
+template <typename T>
+__device__ __forceinline__ float round_to(float v);
+template <>
+__device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float round_to<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+template <typename T, int E>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         T* __restrict__ y, T* __restrict__ s_out, float* __restrict__ mean_out,
+                                                         float* __restrict__ rstd_out, long long M, float eps, float clamp) {
+  constexpr int D = 64 * E;
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * 4;
+  float g[E], b[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) g[i] = gamma[lane * E + i], b[i] = beta[lane * E + i];
+  for (long long row = wave; row < M; row += n_waves) {
+    float v[E];
+    load_vec<T, E>(x + row * D + lane * E, v);
+    if (res) {
+      float r[E];
+      load_vec<T, E>(res + row * D + lane * E, r);
+#pragma unroll
+      for (int i = 0; i < E; ++i) v[i] += r[i];
+    }
+    if (clamp > 0.f) {
+#pragma unroll
+      for (int i = 0; i < E; ++i) v[i] = fminf(fmaxf(v[i], -clamp), clamp);
+    }
+    if (s_out) {  // the normalised quantity as the backward will read it (rounded to T)
+      store_vec<T, E>(s_out + row * D + lane * E, v);
+#pragma unroll
+      for (int i = 0; i < E; ++i) v[i] = round_to<T>(v[i]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; ++i) sum += v[i];
+    const float mean = group_sum<64>(sum) * (1.f / D);
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; ++i) var += (v[i] - mean) * (v[i] - mean);
+    const float rstd = rsqrtf(group_sum<64>(var) * (1.f / D) + eps);
+    float o[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) o[i] = (v[i] - mean) * rstd * g[i] + b[i];
+    store_vec<T, E>(y + row * D + lane * E, o);
+    if (lane == 0) mean_out[row] = mean, rstd_out[row] = rstd;
+  }
+}
+
+template <typename T, int E>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ s,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                         const float* __restrict__ rstd_in, T* __restrict__ ds,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, long long M,
+                                                         float clamp) {
+  constexpr int D = 64 * E;
+  __shared__ float red[2][4][D];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long wave = (long long)blockIdx.x * 4 + w, n_waves = (long long)gridDim.x * 4;
+  float g[E], ag[E], ab[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) g[i] = gamma[lane * E + i], ag[i] = 0.f, ab[i] = 0.f;
+  for (long long row = wave; row < M; row += n_waves) {
+    float d[E], v[E];
+    load_vec<T, E>(dy + row * D + lane * E, d);
+    load_vec<T, E>(s + row * D + lane * E, v);
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float c1 = 0.f, c2 = 0.f, xh[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      xh[i] = (v[i] - mean) * rstd;
+      const float dg = d[i] * g[i];
+      c1 += dg;
+      c2 += dg * xh[i];
+      ag[i] += d[i] * xh[i];
+      ab[i] += d[i];
+    }
+    c1 = group_sum<64>(c1) * (1.f / D);
+    c2 = group_sum<64>(c2) * (1.f / D);
+    float o[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      o[i] = rstd * (d[i] * g[i] - c1 - xh[i] * c2);
+      if (clamp > 0.f && (v[i] <= -clamp || v[i] >= clamp)) o[i] = 0.f;  // clamp's gradient (saturated: 0)
+    }
+    store_vec<T, E>(ds + row * D + lane * E, o);
+  }
+#pragma unroll
+  for (int i = 0; i < E; ++i) red[0][w][lane * E + i] = ag[i], red[1][w][lane * E + i] = ab[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
+template <typename T, int E>
+static int launch_ln(bool fwd, const void* a, const void* b, const float* gamma, const float* beta, void* out, void* s_out,
+                     float* mean, float* rstd, float* dgamma, float* dbeta, long long M, float eps, float clamp, hipStream_t st) {
+  long long blocks = (M + 3) / 4;
+  if (blocks > 2048) blocks = 2048;  // grid-stride over rows: bounded atomic traffic in the backward
+  if (fwd)
+    hipLaunchKernelGGL((add_ln_fwd_kernel<T, E>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)a, (const T*)b, gamma, beta,
+                       (T*)out, (T*)s_out, mean, rstd, M, eps, clamp);
+  else
+    hipLaunchKernelGGL((add_ln_bwd_kernel<T, E>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)a, (const T*)b, gamma, mean, rstd,
+                       (T*)out, dgamma, dbeta, M, clamp);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
+#define DFINE_LN_DISPATCH(CALL)                                 \
+  do {                                                          \
+    if (dtype == DFINE_DT_BF16) {                               \
+      if (D == 128) return CALL(bf16_t, 2);                     \
+      if (D == 256) return CALL(bf16_t, 4);                     \
+      if (D == 512) return CALL(bf16_t, 8);                     \
+    } else if (dtype == DFINE_DT_F32) {                         \
+      if (D == 128) return CALL(float, 2);                      \
+      if (D == 256) return CALL(float, 4);                      \
+    }                                                           \
+    return DFINE_E_UNSUPPORTED;                                 \
+  } while (0)
+
+}  // namespace dfine
+
+using namespace dfine;
+
+extern "C" int dfine_add_layernorm_fwd(const void* x, const void* res, int dtype, const float* gamma, const float* beta,
+                                       void* y, void* s_out, float* mean, float* rstd, long long M, int D, float eps,
+                                       float clamp, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd) return DFINE_E_BADARG;
+  if (M <= 0 || D <= 0 || eps <= 0.f) return DFINE_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+#define FWD(T, E) launch_ln<T, E>(true, x, res, gamma, beta, y, s_out, mean, rstd, nullptr, nullptr, M, eps, clamp, st)
+  DFINE_LN_DISPATCH(FWD);
+#undef FWD
+}
+
+extern "C" int dfine_add_layernorm_bwd(const void* dy, const void* s, int dtype, const float* gamma, const float* mean,
+                                       const float* rstd, void* ds, float* dgamma, float* dbeta, long long M, int D,
+                                       float clamp, void* stream) {
+  if (!dy || !s || !gamma || !mean || !rstd || !ds || !dgamma || !dbeta) return DFINE_E_BADARG;
+  if (M <= 0 || D <= 0) return DFINE_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+#define BWD(T, E) launch_ln<T, E>(false, dy, s, gamma, nullptr, ds, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dgamma, dbeta, M, 0.f, clamp, st)
+  DFINE_LN_DISPATCH(BWD);
+#undef BWD
+}

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .configs import ModelSpec
-from .layers import MLP, ConvNorm, Linear, PackedSelfAttention, bias_for_prior
+from .layers import MLP, ConvNorm, LayerNorm, Linear, PackedSelfAttention, bias_for_prior
 from .targets import TargetBatch
 
 
@@ -97,32 +97,32 @@ class Gate(nn.Module):
         self.gate = Linear(2 * dim, 2 * dim)
         nn.init.constant_(self.gate.bias, bias_for_prior(0.5))
         nn.init.zeros_(self.gate.weight)
-        self.norm = nn.LayerNorm(dim)
+        self.norm = LayerNorm(dim)
 
     def forward(self, a, b):
         g1, g2 = torch.sigmoid(self.gate(torch.cat([a, b], -1))).chunk(2, -1)
-        return self.norm(g1 * a + g2 * b)
+        return self.norm(g1 * a, g2 * b)
 
 
 class DecoderLayer(nn.Module):
     def __init__(self, dim, n_head, ffn, num_points):
         super().__init__()
         self.self_attn = PackedSelfAttention(dim, n_head)
-        self.norm1 = nn.LayerNorm(dim)
+        self.norm1 = LayerNorm(dim)
         self.cross_attn = MSDeformableAttention(dim, n_head, num_points)
         self.gateway = Gate(dim)
         self.linear1 = Linear(dim, ffn)
         self.linear2 = Linear(ffn, dim)
-        self.norm3 = nn.LayerNorm(dim)
+        self.norm3 = LayerNorm(dim)
         nn.init.xavier_uniform_(self.linear1.weight)
         nn.init.xavier_uniform_(self.linear2.weight)
 
     def forward(self, tgt, ref_boxes, value, spatial_shapes, blocked, pos, sink=None, finalize=True):
-        tgt = self.norm1(tgt + self.self_attn(tgt + pos, tgt, blocked))
+        tgt = self.norm1(tgt, self.self_attn(tgt + pos, tgt, blocked))
         cross = self.cross_attn(tgt + pos, ref_boxes, value, spatial_shapes, sink, finalize).to(tgt.dtype)
         tgt = self.gateway(tgt, cross)
         ffn = self.linear2(F.relu(self.linear1(tgt)))
-        return self.norm3((tgt + ffn).clamp(-65504, 65504))
+        return self.norm3(tgt, ffn, clamp=65504.0)
 
 
 class LQE(nn.Module):
@@ -204,7 +204,7 @@ class DFINETransformer(nn.Module):
         self.query_pos_head = MLP(4, 2 * hid, hid, 2)
         self.enc_output = nn.Sequential()
         self.enc_output.add_module("proj", Linear(hid, hid))
-        self.enc_output.add_module("norm", nn.LayerNorm(hid))
+        self.enc_output.add_module("norm", LayerNorm(hid))
         self.enc_score_head = Linear(hid, num_classes)
         self.enc_bbox_head = MLP(hid, hid, 4, 3)
         self.dec_score_head = nn.ModuleList(Linear(hid, num_classes) for _ in range(spec.num_layers))

@@ -7,7 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .configs import ModelSpec
-from .layers import ConvNorm, Linear, PackedSelfAttention
+from .layers import ConvNorm, LayerNorm, Linear, PackedSelfAttention
 
 
 class RepVgg(nn.Module):
@@ -70,12 +70,12 @@ class EncoderLayer(nn.Module):
         self.self_attn = PackedSelfAttention(dim, n_head)
         self.linear1 = Linear(dim, ffn)
         self.linear2 = Linear(ffn, dim)
-        self.norm1 = nn.LayerNorm(dim)
-        self.norm2 = nn.LayerNorm(dim)
+        self.norm1 = LayerNorm(dim)
+        self.norm2 = LayerNorm(dim)
 
     def forward(self, x, pos):
-        x = self.norm1(x + self.self_attn(x + pos, x))
-        return self.norm2(x + self.linear2(F.gelu(self.linear1(x))))
+        x = self.norm1(x, self.self_attn(x + pos, x))
+        return self.norm2(x, self.linear2(F.gelu(self.linear1(x))))
 
 
 class _LayerStack(nn.Module):  # gives the reference's key path ``encoder.0.layers.0``

@@ -109,6 +109,24 @@ class ConvNorm(nn.Module):
         self._pending_batches = 0
 
 
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters / state_dict keys) with an optional fused residual and clamp:
+    ``norm(x, res, clamp)`` = ``layer_norm(clamp(x + res))``. On the GPU this is one HIP launch per direction
+    in the activations' dtype (bf16 under autocast; the stock op would run in fp32 between two casts)."""
+
+    def forward(self, x, res=None, clamp=None):
+        D = self.normalized_shape[0]
+        if len(self.normalized_shape) == 1 and self.elementwise_affine and x.is_cuda:
+            dt = torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
+            if ops.add_layer_norm_supported(x.to(dt) if x.dtype != dt else x, D):
+                return ops.add_layer_norm(x.to(dt), res, self.weight, self.bias, self.eps, clamp)
+        if res is not None:
+            x = x + res
+        if clamp:
+            x = x.clamp(-clamp, clamp)
+        return super().forward(x)
+
+
 class Linear(nn.Linear):
     """nn.Linear (same parameters / state_dict keys) whose bf16 training path goes through
     ``ops.linear``: library GEMMs for y and dx, the HIP split-M kernel for dW / db."""

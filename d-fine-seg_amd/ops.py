@@ -544,6 +544,67 @@ def stem_pool_supported(x):
     return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0
 
 
+class _AddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, eps, clamp):
+        _lib.require_gpu(x, weight, bias)
+        lib = _lib.load()
+        D = x.shape[-1]
+        xc = x.contiguous()
+        rc_ = res.to(xc.dtype).contiguous() if res is not None else None
+        M = xc.numel() // D
+        y = torch.empty_like(xc)
+        keep_s = res is not None or clamp > 0
+        s = torch.empty_like(xc) if keep_s else xc
+        mean = torch.empty(M, dtype=torch.float32, device=xc.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=xc.device)
+        g32, b32 = weight.detach().float(), bias.detach().float()
+        es = xc.element_size()
+        with _lib.timed("add_layernorm_fwd", xc.numel() * es * (2 + (1 if res is not None else 0) + (1 if keep_s else 0))):
+            rc = lib.dfine_add_layernorm_fwd(_lib.ptr(xc), _lib.ptr(rc_), _lib.dtype_code(xc), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(y),
+                                             _lib.ptr(s) if keep_s else None, _lib.ptr(mean), _lib.ptr(rstd), M, D, eps, clamp,
+                                             _lib.stream_ptr())
+        _lib.check(rc, "dfine_add_layernorm_fwd")
+        ctx.save_for_backward(s, g32, mean, rstd)
+        ctx.meta = (weight, bias, clamp, res is not None, res.dtype if res is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        s, g32, mean, rstd = ctx.saved_tensors
+        weight, bias, clamp, has_res, res_dtype = ctx.meta
+        lib = _lib.load()
+        D = s.shape[-1]
+        M = s.numel() // D
+        gy = gy.to(s.dtype).contiguous()
+        ds = torch.empty_like(s)
+        direct = (DIRECT_WGRAD_ACCUM and weight.grad is not None and bias.grad is not None and weight.grad.dtype == torch.float32
+                  and weight.grad.is_contiguous() and bias.grad.is_contiguous())
+        if direct:
+            dg, db = weight.grad, bias.grad
+        else:
+            dg, db = zeros_f32(D, s.device), zeros_f32(D, s.device)
+        with _lib.timed("add_layernorm_bwd", s.numel() * s.element_size() * 3):
+            rc = lib.dfine_add_layernorm_bwd(_lib.ptr(gy), _lib.ptr(s), _lib.dtype_code(s), _lib.ptr(g32), _lib.ptr(mean), _lib.ptr(rstd),
+                                             _lib.ptr(ds), _lib.ptr(dg), _lib.ptr(db), M, D, clamp, _lib.stream_ptr())
+        _lib.check(rc, "dfine_add_layernorm_bwd")
+        d_res = (ds if res_dtype == ds.dtype else ds.to(res_dtype)) if has_res else None
+        if direct:
+            return ds, d_res, None, None, None, None
+        return ds, d_res, dg.clone().to(weight.dtype), db.clone().to(bias.dtype), None, None
+
+
+def add_layer_norm_supported(x, dim):
+    return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and (dim in (128, 256) or (dim == 512 and x.dtype == torch.bfloat16))
+
+
+def add_layer_norm(x, res, weight, bias, eps=1e-5, clamp=None):
+    """``F.layer_norm(clamp(x + res), (D,), weight, bias, eps)`` in x's dtype (statistics in fp32), one launch
+    forward and one backward; ``res`` / ``clamp`` optional. Reference: the post-norm blocks of
+    dfine_decoder.py:233-271 and hybrid_encoder.py:274-290."""
+    return _AddLayerNorm.apply(x, res, weight, bias, float(eps), float(clamp) if clamp else 0.0)
+
+
 class _MaskRowStats(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, tgt, alpha):

@@ -281,6 +281,26 @@ int dfine_mask_loss_stats(const void* logits, int dtype, const float* tgt, const
 int dfine_mask_loss_grad(const void* logits, int dtype, const float* tgt, const float* alpha, const float* g_stats,
                          void* d_logits, int B, int M, int G, int HW, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Residual add + LayerNorm over the last dimension (post-norm blocks: reference
+ * src/d_fine/arch/dfine_decoder.py:233-271 `norm1(tgt + attn)`, `norm3(clamp(tgt + ffn))`, Gate;
+ * hybrid_encoder.py:274-290), in the activations' dtype, statistics in fp32:
+ *     s = clamp(x + res, -clamp, clamp)   (res may be NULL; clamp <= 0: none)
+ *     y = (s - mean(s)) * rsqrt(var(s) + eps) * gamma + beta
+ *   x, res, y, s_out, dy, s, ds [M, D] bf16 or f32 (dtype); gamma, beta, dgamma, dbeta f32 [D];
+ *   mean, rstd f32 [M]. s_out (may be NULL) receives s rounded to the dtype -- pass it (or x when
+ *   res is NULL and clamp <= 0) to the backward as `s`; the statistics are taken on the rounded s.
+ * Backward: ds = d(loss)/d(s) (= gradient of both x and res; 0 where the clamp saturated);
+ *   dgamma / dbeta are ACCUMULATED with float atomics.
+ * D in {128, 256, 512} (512: bf16 only).
+ * ------------------------------------------------------------------------------------- */
+int dfine_add_layernorm_fwd(const void* x, const void* res, int dtype, const float* gamma, const float* beta, void* y,
+                            void* s_out, float* mean, float* rstd, long long M, int D, float eps, float clamp,
+                            void* stream);
+int dfine_add_layernorm_bwd(const void* dy, const void* s, int dtype, const float* gamma, const float* mean,
+                            const float* rstd, void* ds, float* dgamma, float* dbeta, long long M, int D, float clamp,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif
