@@ -277,7 +277,10 @@ class DFINECriterion(nn.Module):
                 mask_terms({"pred_mask_embed": outputs["dn_pred_mask_embed"]}, dn_pairs, "_dn_final")
             head(outputs["dn_pre_outputs"], "_dn_pre", None, local=True, dn=(dn_assign, dn_nb))
             mask_terms(outputs["dn_pre_outputs"], dn_pairs, "_dn_pre")
-        return {k: torch.nan_to_num(v, nan=0.0) for k, v in losses.items()}
+        # the reference's per-term nan_to_num (dfine_criterion.py:576-578) as ONE launch over the stacked terms
+        names = list(losses.keys())
+        clean = torch.nan_to_num(torch.stack([losses[k] for k in names]), nan=0.0)
+        return dict(zip(names, clean.unbind(0)))
 
     # ------------------------------------------------------------------ per-head loss terms: HIP
     def _fused_heads(self, tb, go, gt_of_query, num_boxes, num_boxes_go, fdr, losses):
