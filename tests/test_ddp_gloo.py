@@ -190,7 +190,7 @@ images, targets = synthetic_batch(2, 320, 320, 80, 4, seed=1, device="cuda")
 losses = []
 for reducer in (None, FlatGradAllReduce):
     torch.manual_seed(0)
-    trainer = TrainStep("n", 80, False, (320, 320), "cuda", grad_reducer=reducer, total_steps=100, graph_warmup=2)
+    trainer = TrainStep("n", 80, False, (320, 320), "cuda", grad_reducer=reducer, total_steps=100, graph_warmup=2, amp=False)
     out = []
     for i in range(5):
         torch.manual_seed(10 + i)
@@ -200,7 +200,7 @@ for reducer in (None, FlatGradAllReduce):
     assert isinstance(next(iter(trainer._graphs.values()))[0], _SplitGraph) == (reducer is not None)
     assert float(trainer.flat.grads.abs().max()) == 0.0
 for a, b in zip(*losses):
-    assert abs(a - b) <= 2e-2 * abs(a), losses  # bf16 steps, atomics order: same trajectory within noise
+    assert abs(a - b) <= 5e-3 * abs(a), losses  # fp32 steps; float-atomic order is the only run-to-run difference
 dist.destroy_process_group()
 print("RCCL_GRAPH_OK")
 """
