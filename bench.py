@@ -97,7 +97,8 @@ TIMER_TO_DEVICE_KERNEL = {
     "dwconv_fwd": "dwconv_fwd_kernel", "dwconv_bwd_data": "dwconv_bwd_data_kernel", "dwconv_bwd_weight": "dwconv_bwd_weight_kernel",
     "criterion_head": "criterion_head_kernel", "grad_sumsq": "grad_sumsq_kernel", "adamw_ema_step": "adamw_ema_kernel",
     "fdr_head_fwd": "fdr_head_fwd_kernel", "fdr_head_bwd": "fdr_head_bwd_kernel", "stem_pool_fwd": "pool_fwd_kernel",
-    "stem_pool_bwd": "pool_bwd_kernel",
+    "stem_pool_bwd": "pool_bwd_kernel", "add_layernorm_fwd": "add_ln_fwd_kernel", "add_layernorm_bwd": "add_ln_bwd_kernel",
+    "mask_loss_stats": "mask_stats_kernel", "mask_loss_grad": "mask_grad_kernel",
 }
 
 
