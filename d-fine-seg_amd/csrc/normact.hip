@@ -254,8 +254,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         const float dz = d[i] * ls * act_grad(z, g.act);
         acc[0][i] += dz;
         acc[1][i] += dz * xhat;
-        acc[2][i] += d[i] * act_fwd(z, g.act);
-        acc[3][i] += d[i];
+        if (g.has_lab) {  // d lab_scale / d lab_bias only; without LAB this saves SiLU's second exponential
+          acc[2][i] += d[i] * act_fwd(z, g.act);
+          acc[3][i] += d[i];
+        }
       }
     }
   }
