@@ -196,6 +196,15 @@ class DFINECriterion(nn.Module):
         return b.to(device, non_blocking=True), g.to(device, non_blocking=True)
 
     def forward(self, outputs, targets=None):
+        """match() -> the one collective of the criterion -> compute_losses(). A captured data-parallel step runs the
+        two halves in separate graphs with the all-reduce between their replays (train.TrainStep)."""
+        state = self.match(outputs, targets)
+        self.reduce_normalisers(state)
+        return self.compute_losses(outputs, state)
+
+    def match(self, outputs, targets=None):
+        """All matchings of the step at once (matcher.py:52-130 x (L+2)) and the local normaliser counts:
+        state["norm"] = [matched queries of the GO union, ground truths] on this rank (fp32 [2])."""
         spec, C = self.spec, self.num_classes
         dev = outputs["pred_logits"].device
         tb = outputs.get("targets")
@@ -204,20 +213,30 @@ class DFINECriterion(nn.Module):
         aux, enc = outputs["aux_outputs"], outputs["enc_aux_outputs"]
         main = {k: outputs[k] for k in ("pred_logits", "pred_boxes", "pred_corners", "ref_points", "pred_mask_embed") if k in outputs}
         heads = [main] + list(aux) + [outputs["pre_outputs"]] + list(enc)
-        # ---- all matchings of the step at once (matcher.py:52-130 x (L+2))
         logits = torch.stack([h["pred_logits"].detach().float() for h in heads])
         boxes = torch.stack([h["pred_boxes"].detach().float() for h in heads])
         gt_of_query, query_of_gt = ops.hungarian_match(
             logits, boxes, tb.labels, tb.boxes, tb.counts, spec.match_alpha, spec.match_gamma,
             spec.cost_class, spec.cost_bbox, spec.cost_giou)
         go = ops.go_union(gt_of_query)
-        # ---- normalisers: one 2-float all-reduce (dfine_criterion.py:436-453 issues two)
         norm = torch.stack([(go >= 0).sum().float(), tb.counts.sum().float()])
-        world = 1
+        return {"tb": tb, "main": main, "gt_of_query": gt_of_query, "query_of_gt": query_of_gt, "go": go, "norm": norm}
+
+    @staticmethod
+    def reduce_normalisers(state):
+        """num_boxes / num_boxes_go averaged over the ranks: ONE 2-float all-reduce, in place on state["norm"]
+        (dfine_criterion.py:436-453 issues two all-reduces and two .item())."""
         if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(norm)
-            world = dist.get_world_size()
-        norm = (norm / world).clamp(min=1)
+            dist.all_reduce(state["norm"])
+            state["norm"].div_(dist.get_world_size())
+        return state
+
+    def compute_losses(self, outputs, state):
+        spec, C = self.spec, self.num_classes
+        dev = outputs["pred_logits"].device
+        tb, main, gt_of_query, query_of_gt, go = state["tb"], state["main"], state["gt_of_query"], state["query_of_gt"], state["go"]
+        aux, enc = outputs["aux_outputs"], outputs["enc_aux_outputs"]
+        norm = state["norm"].clamp(min=1)
         num_boxes_go, num_boxes = norm[0], norm[1]
 
         fdr = outputs.get("fdr")

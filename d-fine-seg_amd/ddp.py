@@ -16,9 +16,9 @@ C1-C3 in SURVEY.md 2.3).
 
 Two exchange schedules over the same flat buffer:
 
-  * ``FlatGradAllReduce`` (bench.py's default for N > 1): forward+backward and the optimizer tail are
-    each ONE captured hipGraph; between the two replays the whole gradient buffer is averaged with a
-    single RCCL all-reduce (78 MB for D-FINE-m: ~2-3 ms over xGMI against a ~50 ms step). No overlap
+  * ``FlatGradAllReduce`` (bench.py's default for N > 1): forward+matching, losses+backward and the
+    optimizer tail are captured hipGraphs; between their replays run the criterion's 2-float all-reduce
+    and ONE RCCL all-reduce that averages the whole gradient buffer (78 MB for D-FINE-m: ~2-3 ms over xGMI against a ~50 ms step). No overlap
     with backward, but no per-kernel launch cost either -- eager launching costs this model ~40 ms of
     host time per step, far more than the exposed collective;
   * ``BucketedGradReducer``: eager step, buckets reduced on a side stream as backward fills them.

@@ -62,13 +62,16 @@ class ModelEMA:
 
 
 class _SplitGraph:
-    """forward/backward graph -> gradient all-reduce -> optimizer graph, replayed as one step."""
+    """Data-parallel step: graph(forward + matching) -> 2-float all-reduce -> graph(losses + backward) ->
+    gradient all-reduce -> graph(optimizer), replayed as one step. The collectives stay outside the captures."""
 
-    def __init__(self, head, reducer, tail):
-        self.head, self.reducer, self.tail = head, reducer, tail
+    def __init__(self, head, reduce_norm, middle, reducer, tail):
+        self.head, self.reduce_norm, self.middle, self.reducer, self.tail = head, reduce_norm, middle, reducer, tail
 
     def replay(self):
         self.head.replay()
+        self.reduce_norm()
+        self.middle.replay()
         self.reducer.reduce()
         self.tail.replay()
 
@@ -115,17 +118,26 @@ class TrainStep:
         self.model.train()
 
     # ------------------------------------------------------------------ one step, device side
-    def _forward_backward(self, images, tb):
+    def _forward_match(self, images, tb):
+        """Model forward and the matchings; returns (outputs, criterion state) -- no collective inside."""
         from . import ops
 
         if ops.zero_arena is not None:
             ops.zero_arena.reset()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
             out = self.model(images, targets=tb)
-        losses = self.criterion(out)  # fp32, outside autocast like train.py:548-549
+        return out, self.criterion.match(out)  # fp32, outside autocast like train.py:548-549
+
+    def _loss_backward(self, out, state):
+        losses = self.criterion.compute_losses(out, state)
         loss = torch.stack(list(losses.values())).sum()  # one reduction instead of a chain of ~50 adds
         loss.backward()
         return loss.detach()
+
+    def _forward_backward(self, images, tb):
+        out, state = self._forward_match(images, tb)
+        self.criterion.reduce_normalisers(state)  # the criterion's one collective (2 floats)
+        return self._loss_backward(out, state)
 
     def _optimizer_tail(self):
         self.optimizer.launch()  # clip + AdamW + EMA(params) + bf16 shadow + zero grads
@@ -190,10 +202,15 @@ class TrainStep:
             with torch.cuda.graph(graph):
                 s_loss = self._body(s_images, s_tb)
             return graph, s_images, s_tb, s_loss
-        # data parallel: two graphs with the gradient all-reduce (not captured) between their replays
+        # data parallel: three graphs; the two collectives (2-float normaliser all-reduce of the criterion,
+        # gradient all-reduce) run between their replays and are never part of a capture
         with torch.cuda.graph(graph):
-            s_loss = self._forward_backward(s_images, s_tb)
+            out, state = self._forward_match(s_images, s_tb)
+        middle = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(middle, pool=graph.pool()):
+            s_loss = self._loss_backward(out, state)
         tail = torch.cuda.CUDAGraph()
         with torch.cuda.graph(tail, pool=graph.pool()):
             self._optimizer_tail()
-        return _SplitGraph(graph, self.grad_reducer, tail), s_images, s_tb, s_loss
+        reduce_norm = lambda: self.criterion.reduce_normalisers(state)
+        return _SplitGraph(graph, reduce_norm, middle, self.grad_reducer, tail), s_images, s_tb, s_loss

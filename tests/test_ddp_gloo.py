@@ -136,7 +136,7 @@ def test_criterion_normaliser_allreduce_is_single_message():
 
     from dfine_seg_amd import criterion
 
-    src = inspect.getsource(criterion.DFINECriterion.forward)
+    src = inspect.getsource(criterion.DFINECriterion)
     assert src.count("dist.all_reduce(") == 1
 
 
