@@ -210,7 +210,7 @@ def main():
                               "(the timed steps replay a hipGraph)" if graph_was_on else "HIP events over eager steps",
                     "kernels": kernels}
         result = {
-            "metric": "images/sec training, D-FINE-m 640x640 bf16",
+            "metric": f"images/sec training, D-FINE-{args.model} {args.img}x{args.img} bf16",  # default = BASELINE.json's metric
             "value": round(args.batch * world * args.steps / elapsed, 2),
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
