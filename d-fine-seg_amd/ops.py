@@ -784,6 +784,10 @@ class _DenseConv(torch.autograd.Function):
     def forward(ctx, x, weight, stride, padding):
         w16 = bf16_of(weight)
         x16 = x.to(torch.bfloat16)
+        if not x16.is_contiguous(memory_format=torch.channels_last):
+            # a channel slice (chunk / cat gradient views): the library conv would copy it internally and the
+            # backward's wgrad again -- make the one dense copy here and keep it
+            x16 = x16.contiguous(memory_format=torch.channels_last)
         y = torch.nn.functional.conv2d(x16, w16, None, stride, padding)
         ctx.save_for_backward(x16, w16)
         ctx.weight, ctx.geom = weight, (stride, padding)

@@ -15,10 +15,13 @@ for _ in range(3):
 log = collections.defaultdict(lambda: [0, 0])
 
 def site():
-    for fr in reversed(traceback.extract_stack()[:-2]):
-        if "d-fine-seg_amd" in fr.filename:
-            return f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.line[:60] if fr.line else ''}"
-    return "?"
+    frames = [fr for fr in traceback.extract_stack()[:-2] if "d-fine-seg_amd" in fr.filename]
+    if not frames:
+        return "?"
+    fr = frames[-1]
+    if fr.name == "_nhwc" and len(frames) > 1:  # the helper: report its caller
+        fr = frames[-2]
+    return f"{os.path.basename(fr.filename)}:{fr.lineno} [{fr.name}] {fr.line[:50] if fr.line else ''}"
 
 orig_cat, orig_contig, orig_pad, orig_clone = torch.cat, torch.Tensor.contiguous, F.pad, torch.Tensor.clone
 def cat(ts, *a, **k):
@@ -28,7 +31,7 @@ def cat(ts, *a, **k):
 def contig(self, *a, **k):
     out = orig_contig(self, *a, **k)
     if out.data_ptr() != self.data_ptr():
-        e = log[("contiguous", site())]; e[0] += out.numel() * out.element_size(); e[1] += 1
+        e = log[("contiguous", site() + f" {tuple(self.shape)}")]; e[0] += out.numel() * out.element_size(); e[1] += 1
     return out
 def pad(x, *a, **k):
     out = orig_pad(x, *a, **k)
