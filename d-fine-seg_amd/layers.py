@@ -82,15 +82,16 @@ class ConvNorm(nn.Module):
         act_name = act if act is not None else self.act_name
         norm = getattr(self, self.norm_name)
         lab = getattr(self, "lab", None)
-        fused = (isinstance(norm, nn.BatchNorm2d) and ops.batch_norm_act_supported(x, conv.out_channels)
-                 and (self.training or not torch.is_grad_enabled()))
-        if fused:  # HIP: norm + addend + activation + LAB in 2 kernels (2 more in backward)
-            if self.training:
+        frozen = isinstance(norm, FrozenBatchNorm2d)
+        fused = (isinstance(norm, nn.BatchNorm2d) or frozen) and ops.batch_norm_act_supported(x, conv.out_channels)
+        if fused:  # HIP: norm + addend + activation + LAB in 2 kernels (2 more in backward); frozen/eval: 1 + 1
+            batch_stats = self.training and not frozen
+            if batch_stats:
                 self._pending_batches += 1
             return ops.batch_norm_act(
                 x, norm.weight, norm.bias, norm.running_mean, norm.running_var, act_name,
                 lab.scale if lab is not None else None, lab.bias if lab is not None else None, addend,
-                training=self.training, momentum=norm.momentum, eps=norm.eps)
+                training=batch_stats, momentum=getattr(norm, "momentum", 0.1) or 0.1, eps=norm.eps)
         x = norm(x)
         if addend is not None:
             x = x + addend

@@ -351,7 +351,8 @@ def _nhwc(t):
 
 
 class _BatchNormAct(torch.autograd.Function):
-    """Training-mode BN + addend + activation + LAB; see include/dfine_hip.h (dfine_bn_act_*)."""
+    """BN (batch statistics, or frozen/running statistics) + addend + activation + LAB; see
+    include/dfine_hip.h (dfine_bn_act_*)."""
 
     @staticmethod
     def forward(ctx, x, addend, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, eps, momentum, training):
@@ -379,6 +380,9 @@ class _BatchNormAct(torch.autograd.Function):
         with _lib.timed("bn_apply", (xl.numel() + y.numel() + (al.numel() if al is not None else 0)) * es, f"{n_pix}x{C}"):
             rc = rc or lib.dfine_bn_act_fwd(*args, 2, _lib.stream_ptr())
         _lib.check(rc, "dfine_bn_act_fwd")
+        if not training:  # frozen / eval statistics: the backward kernel reads them from the same two buffers
+            save_mean = running_mean.detach().float()
+            save_rstd = torch.rsqrt(running_var.detach().float() + eps)
         ctx.save_for_backward(xl, al, g32, b32, save_mean, save_rstd, ls32)
         ctx.cfg = (act, eps, int(training), gamma.dtype, lab_scale.dtype if lab_scale is not None else None)
         ctx.params = (gamma, beta, lab_scale, lab_bias)
@@ -388,8 +392,6 @@ class _BatchNormAct(torch.autograd.Function):
     def backward(ctx, grad_y):
         xl, al, g32, b32, save_mean, save_rstd, ls32 = ctx.saved_tensors
         act, eps, training, g_dtype, lab_dtype = ctx.cfg
-        if not training:
-            raise _lib.DfineHipError("fused BatchNorm backward is only built for batch statistics (training mode)")
         lib = _lib.load()
         n_pix, C = xl.numel() // xl.shape[-1], xl.shape[-1]
         gy = _nhwc(grad_y.to(xl.dtype))
@@ -400,7 +402,8 @@ class _BatchNormAct(torch.autograd.Function):
         red, dgamma, dbeta, dlab = ws[: 64 * C], ws[64 * C : 65 * C], ws[65 * C : 66 * C], ws[66 * C :]
         gamma_p, beta_p, ls_p, lb_p = ctx.params
         plist = [gamma_p, beta_p] + ([ls_p, lb_p] if ls32 is not None else [])
-        direct = DIRECT_WGRAD_ACCUM and all(
+        wants_param_grads = any(p.requires_grad for p in plist)  # FrozenBatchNorm2d: buffers, no LAB -> dx only
+        direct = DIRECT_WGRAD_ACCUM and wants_param_grads and all(
             p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in plist)
         dls, dlb = dlab[0:1], dlab[1:2]
         if direct:  # accumulate straight into the fp32 .grad views (no AccumulateGrad add kernels)
@@ -413,12 +416,14 @@ class _BatchNormAct(torch.autograd.Function):
                 _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(ls32), _lib.ptr(red), _lib.ptr(dx), _lib.ptr(dadd), _lib.ptr(dgamma),
                 _lib.ptr(dbeta), _lib.ptr(dls) if ls32 is not None else None, _lib.ptr(dlb) if ls32 is not None else None,
                 n_pix, C, _ACT_CODES[act], training, eps)
-        with _lib.timed("bn_bwd_reduce", (xl.numel() + gy.numel() + n_add) * es, f"{n_pix}x{C}"):
-            rc = lib.dfine_bn_act_bwd(*args, 1, _lib.stream_ptr())
+        rc = 0
+        if training or wants_param_grads:  # the reductions feed the batch-statistics terms and the parameter gradients
+            with _lib.timed("bn_bwd_reduce", (xl.numel() + gy.numel() + n_add) * es, f"{n_pix}x{C}"):
+                rc = lib.dfine_bn_act_bwd(*args, 1, _lib.stream_ptr())
         with _lib.timed("bn_bwd_dx", (xl.numel() + 2 * gy.numel() + 2 * n_add) * es, f"{n_pix}x{C}"):
             rc = rc or lib.dfine_bn_act_bwd(*args, 2, _lib.stream_ptr())
         _lib.check(rc, "dfine_bn_act_bwd")
-        if direct:
+        if direct or not wants_param_grads:
             return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None) + (None,) * 10
         return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None,
                 dgamma.to(g_dtype), dbeta.to(g_dtype), None, None,

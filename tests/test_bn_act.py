@@ -81,3 +81,40 @@ def test_eval_mode_uses_running_statistics(hip_lib):
         y = ops.batch_norm_act(x.cuda().contiguous(memory_format=torch.channels_last), gamma.cuda(), beta.cuda(),
                                rm.cuda(), rv.cuda(), "silu", training=False)
     torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("frozen", [True, False])
+@pytest.mark.parametrize("act,with_add", [("relu", False), ("silu", True), (None, False)])
+def test_running_statistics_backward(hip_lib, frozen, act, with_add):
+    """FrozenBatchNorm2d (buffers: only dx / d addend) and eval-mode BatchNorm with trainable affine
+    (dgamma / dbeta too) through the fused kernels, against autograd of the same formula."""
+    from dfine_seg_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    C = 40
+    x = torch.randn(3, C, 11, 7, generator=g)
+    a = torch.randn(3, C, 11, 7, generator=g) if with_add else None
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    gy = torch.randn(3, C, 11, 7, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ar = a.clone().requires_grad_(True) if with_add else None
+    gr, br = gamma.clone().requires_grad_(not frozen), beta.clone().requires_grad_(not frozen)
+    z = F.batch_norm(xr, rm, rv, gr, br, training=False, eps=1e-5)
+    if with_add:
+        z = z + ar
+    ref = {"relu": F.relu, "silu": F.silu, None: lambda t: t}[act](z)
+    ref.backward(gy)
+    cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last)
+    xd = cl(x).requires_grad_(True)
+    ad = cl(a).requires_grad_(True) if with_add else None
+    gd, bd = gamma.cuda().requires_grad_(not frozen), beta.cuda().requires_grad_(not frozen)
+    y = ops.batch_norm_act(xd, gd, bd, rm.cuda(), rv.cuda(), act, None, None, ad, training=False)
+    torch.testing.assert_close(y.cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    y.backward(cl(gy))
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4)
+    if with_add:
+        torch.testing.assert_close(ad.grad.cpu(), ar.grad, rtol=1e-4, atol=1e-4)
+    if not frozen:
+        torch.testing.assert_close(gd.grad.cpu(), gr.grad, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(bd.grad.cpu(), br.grad, rtol=1e-3, atol=1e-3)
