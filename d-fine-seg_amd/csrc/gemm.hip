@@ -198,34 +198,45 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict_
     }
   };
 
-  // Two LDS stages, one barrier per 32-row step. Ring slot k holds a step == k (mod DEPTH); the loop is
-  // unrolled by DEPTH (even) so slots and LDS stages are compile-time indices. Rows at or beyond m_end are
-  // fetched as zeros, so every workgroup simply runs a multiple of DEPTH steps.
+  // Two LDS stages, one barrier per 32-row step, and the MFMA operands double-buffered in registers: while
+  // the MFMAs of step s run, the ds_read_b64_tr_b16 of step s+1 are already in flight (their latency was
+  // exposed at the top of every step before). Ring slot k holds a step == k (mod DEPTH); the loop is
+  // unrolled by DEPTH (even) so slots, LDS stages and fragment buffers are compile-time indices. Rows at or
+  // beyond m_end are fetched as zeros, so every workgroup simply runs a multiple of DEPTH steps.
   const int n_steps = (m_end - m_begin + WG_MSTEP * DEPTH - 1) / (WG_MSTEP * DEPTH) * DEPTH;
+  short8v fa[2][FN], fb[2][FK];
+  auto read_frags = [&](int buf, int stage_idx) {
+    const bf16_t* at = a_tile0 + stage_idx * WG_MSTEP * TN;
+    const bf16_t* bt = b_tile0 + stage_idx * WG_MSTEP * TK;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) fa[buf][i] = tr_frag<TN>(at, wave_n * (TN / 2) + 16 * i, lane);
+#pragma unroll
+    for (int j = 0; j < FK; ++j) fb[buf][j] = tr_frag<TK>(bt, wave_k * (TK / 2) + 16 * j, lane);
+  };
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) fetch(d, m_begin + WG_MSTEP * d);
-  stage(0, 0);
+  stage(0, 0);  // step 0
   fetch(0, m_begin + WG_MSTEP * DEPTH);
+  __syncthreads();
+  read_frags(0, 0);
+  stage(1, 1 % DEPTH);  // step 1
+  fetch(1 % DEPTH, m_begin + WG_MSTEP * (DEPTH + 1));
   __syncthreads();
   for (int s0 = 0; s0 < n_steps; s0 += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-      const bf16_t* at = a_tile0 + (d & 1) * WG_MSTEP * TN;
-      const bf16_t* bt = b_tile0 + (d & 1) * WG_MSTEP * TK;
-      short8v a[FN], b[FK];
-#pragma unroll
-      for (int i = 0; i < FN; ++i) a[i] = tr_frag<TN>(at, wave_n * (TN / 2) + 16 * i, lane);
-#pragma unroll
-      for (int j = 0; j < FK; ++j) b[j] = tr_frag<TK>(bt, wave_k * (TK / 2) + 16 * j, lane);
+      // step s = s0 + d: its operands are in fragment buffer d&1; prefetch step s+1 from the other LDS stage
+      read_frags((d + 1) & 1, (d + 1) & 1);
 #pragma unroll
       for (int i = 0; i < FN; ++i)
 #pragma unroll
-        for (int j = 0; j < FK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-      // step s+1 (ring slot (d+1) % DEPTH, loaded DEPTH steps ago) goes to the other LDS stage, which was
-      // last read one step ago (barrier below); the freed slot takes the loads of step s+1+DEPTH
-      const int slot = (d + 1) % DEPTH;
-      stage((d + 1) & 1, slot);
-      fetch(slot, m_begin + WG_MSTEP * (s0 + d + 1 + DEPTH));
+        for (int j = 0; j < FK; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[d & 1][i], fb[d & 1][j], acc[i][j], 0, 0, 0);
+      // step s+2 (ring slot (d+2) % DEPTH, loaded DEPTH steps ago) goes to LDS stage d&1: that stage held step s,
+      // whose fragments every wave read one iteration ago (before the previous barrier)
+      const int slot = (d + 2) % DEPTH;
+      stage(d & 1, slot);
+      fetch(slot, m_begin + WG_MSTEP * (s0 + d + 2 + DEPTH));
       __syncthreads();
     }
   }
