@@ -148,6 +148,9 @@ int dfine_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* wor
  *       the caller before the call
  *   act: 0 identity, 1 ReLU, 2 SiLU.  training=1: batch statistics, running stats updated
  *   (momentum, unbiased variance); training=0 (forward only): running statistics.
+ *   training=0 in the backward: dx = gamma * rstd * dz with save_mean / save_rstd = the running statistics
+ *       (FrozenBatchNorm2d, src/d_fine/arch/common.py:29-67, and eval-mode BN); phase 1 is then only needed for
+ *       dgamma / dbeta / d lab.
  *   phase: each direction is two kernels (forward: statistics, apply; backward: reductions, dx).
  *       0 = launch both, 1 = only the first, 2 = only the second (so a caller can time them apart).
  * Any C (the widest channel vector <= 16 bytes that divides C is used).
