@@ -118,6 +118,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or args.force_ddp:  # one MIOpen user db / kernel cache per rank: N ranks tuning at once would contend on one sqlite file
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", f"/tmp/miopen_udb_rank{rank}")
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", f"/tmp/miopen_cache_rank{rank}")
+        for var in ("MIOPEN_USER_DB_PATH", "MIOPEN_CUSTOM_CACHE_DIR"):
+            os.makedirs(os.environ[var], exist_ok=True)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     torch.cuda.set_device(local_rank)
