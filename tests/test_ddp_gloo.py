@@ -129,6 +129,30 @@ def test_bucket_assignment_covers_every_trainable_parameter_once():
     assert 1 < len(buckets) <= 3
 
 
+def _norm_worker(rank, world, port, result):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dfine_seg_amd.criterion import DFINECriterion
+
+        state = {"norm": torch.tensor([10.0 + rank, 4.0 * (rank + 1)])}  # [matched queries of the GO union, ground truths]
+        DFINECriterion.reduce_normalisers(state)
+        want = torch.tensor([sum(10.0 + r for r in range(world)) / world, sum(4.0 * (r + 1) for r in range(world)) / world])
+        torch.testing.assert_close(state["norm"], want)
+        result[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_criterion_normalisers_are_averaged_over_ranks_gloo():
+    """num_boxes / num_boxes_go = sum over ranks / world size (dfine_criterion.py:436-453), as one message."""
+    world = 2
+    with mp.Manager() as mgr:
+        result = mgr.dict()
+        mp.spawn(_norm_worker, args=(world, _free_port(), result), nprocs=world, join=True)
+        assert dict(result) == {0: "ok", 1: "ok"}
+
+
 def test_criterion_normaliser_allreduce_is_single_message():
     """The product criterion fuses num_boxes / num_boxes_go into ONE 2-float all-reduce
     (reference: two all-reduces + two .item(), dfine_criterion.py:436-453)."""
