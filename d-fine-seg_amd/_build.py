@@ -46,14 +46,43 @@ def find_hipcc():
     raise RuntimeError("hipcc not found: libdfine_hip.so cannot be built")
 
 
+def _object_path(src):
+    return os.path.join(CSRC_DIR, "build", os.path.basename(src)[:-4] + ".o")
+
+
+def _compile_one(args):
+    src, obj, verbose = args
+    cmd = [find_hipcc(), *[f for f in HIPCC_FLAGS if f != "-shared"], "-c", f"-I{INCLUDE_DIR}", f"-I{CSRC_DIR}", "-o", obj, src]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    return src, proc.returncode, proc.stdout + proc.stderr
+
+
 def build(force=False, verbose=False):
-    """Compile csrc/*.hip into libdfine_hip.so if it is missing or older than its sources."""
+    """Compile csrc/*.hip into libdfine_hip.so if it is missing or older than its sources: one object per
+    source (only the stale ones, in parallel), then one link."""
     if not force and not _stale():
         return LIB_PATH
-    cmd = [find_hipcc(), *HIPCC_FLAGS, f"-I{INCLUDE_DIR}", f"-I{CSRC_DIR}", "-o", LIB_PATH, *sources()]
+    from concurrent.futures import ThreadPoolExecutor
+
+    os.makedirs(os.path.join(CSRC_DIR, "build"), exist_ok=True)
+    headers = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith(".h")]
+    headers += [os.path.join(INCLUDE_DIR, f) for f in os.listdir(INCLUDE_DIR)]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    jobs = []
+    for src in sources():
+        obj = _object_path(src)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            jobs.append((src, obj, verbose))
+    with ThreadPoolExecutor(max_workers=min(8, max(len(jobs), 1))) as pool:
+        for src, rc, log in pool.map(_compile_one, jobs):
+            if rc != 0:
+                raise RuntimeError(f"hipcc failed on {src} ({rc}):\n{log}")
+    cmd = [find_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *[_object_path(s) for s in sources()]]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+        raise RuntimeError(f"hipcc link failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
     return LIB_PATH

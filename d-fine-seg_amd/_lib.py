@@ -41,11 +41,25 @@ SIGNATURES = {
     "dfine_add_layernorm_bwd": [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 6 + [ctypes.c_longlong, _c_int, ctypes.c_float, _c_void_p],
     "dfine_grad_sumsq": [_c_void_p, ctypes.c_longlong, _c_void_p, _c_void_p],
     "dfine_adamw_ema_step": [_c_void_p] * 8 + [ctypes.POINTER(ctypes.c_longlong), _c_int, ctypes.c_longlong, _c_void_p],
+    "dfine_igemm_bf16": [_c_void_p] * 7,
+    "dfine_transpose_weights": [_c_void_p] * 4 + [_c_int, _c_void_p],
+    "dfine_embedding_wgrad": [_c_void_p, _c_void_p, _c_int, _c_void_p, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_void_p],
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
 ABI_VERSION = 1
 _lib = None
+
+IGEMM_MAX_TAPS = 16
+
+
+class IGemmGeom(ctypes.Structure):
+    """dfine_igemm_geom of include/dfine_hip.h (host struct, passed by pointer)."""
+
+    _fields_ = [(n, _c_int) for n in ("M", "N", "K", "lda", "ldb", "ldc", "gather", "PH", "PW", "IH", "IW", "CI", "ntaps",
+                                      "isy", "isx", "OHf", "OWf", "osy", "osx", "ooy", "oox", "act")] + [
+        ("tap_dy", ctypes.c_byte * IGEMM_MAX_TAPS), ("tap_dx", ctypes.c_byte * IGEMM_MAX_TAPS),
+        ("tap_w", ctypes.c_byte * IGEMM_MAX_TAPS)]
 
 
 class DfineHipError(RuntimeError):

@@ -1,0 +1,423 @@
+// Implicit-GEMM convolution / Linear on bf16 MFMA (gfx950), forward and input gradient:
+//
+//     C[m][n] = act( sum_k A(m, k) * Bw[n][k] + bias[n] )          fp32 accumulate, bf16 out
+//
+// One kernel family serves every dense contraction of the step:
+//   * Linear forward       y = x W^T + b           A(m,k) = x[m][k],         Bw = W [N][K]
+//   * Linear input grad    dx = dy W               A(m,k) = dy[m][k],        Bw = W^T [K_in][N_out]
+//   * conv forward         (HGNetv2 ConvBNAct hgnetv2.py:35-80, hybrid_encoder ConvNormLayer :21-45)
+//                          A(m,k) = X[b][py*s + dy(tap)][px*s + dx(tap)][c], k = tap*CI + c, Bw = W [CO][KH][KW][CI]
+//   * conv input grad      the same gather over dY with mirrored taps and Bw = W^T [CI][KH][KW][CO];
+//                          a strided conv's gradient is launched once per input-parity class
+//   * ConvTranspose2d 2x2 s2 (MaskPixelDecoder.upconv, dfine_decoder.py:316-376): four 1-tap launches that
+//     write interleaved output pixels; its input gradient is a 4-tap gather with input stride 2
+// A "tap" is a (dy, dx, weight-slot) triple from a small table, so asymmetric padding (the stem's
+// F.pad(...,(0,1,0,1)) + 2x2 conv, hgnetv2.py:156-166) needs no padded copy: out-of-range taps read zeros.
+//
+// Epilogue (the reason this is not a library call): bias + ReLU, the per-channel sum / sum of squares of
+// the bf16-rounded outputs for the BatchNorm that follows every conv (fp64 atomics into the same replica
+// layout dfine_bn_act_fwd reads, so its statistics pass disappears), and an output row pitch `ldc` so a
+// layer can write straight into its slice of a concat buffer. `lda` likewise lets a layer read a channel
+// slice of a wider map.
+//
+// Mapping: workgroup = 256 threads = 2 x 2 waves, tile BM x BN = 32*FM x 32*FN, K step BK. Both operands are
+// K-contiguous, so MFMA 16x16x32 fragments are plain 16-byte LDS reads (row lane&15, 16-byte chunk lane>>4);
+// the 16-byte chunks of a tile row are XOR-swizzled by row so that every ds_read_b128 lane group covers all
+// 16 slots of the 256-byte bank row (checked exhaustively: conflict-free for BK = 32 and 64). The weight
+// tile is MFMA operand A and the pixel tile operand B: an accumulator register quad then holds 4 CONSECUTIVE
+// output channels of one pixel, the tile goes through LDS once as packed 8-byte writes and leaves as 16-byte
+// row-contiguous stores. Global -> LDS staging is through registers (the gather zero-fills padding taps and
+// rows beyond M), one K step ahead, one barrier per K step. Tiles of one M range share an XCD (its L2 holds
+// the activation rows all N tiles re-read and the halo rows neighbouring M tiles share).
+#include "common.h"
+
+namespace dfine {
+
+typedef short short8v __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+typedef dfine_igemm_geom IGemmGeom;
+
+template <int BK>
+__device__ __forceinline__ int ig_swz(int r) {
+  if (BK == 64) return (r >> 1) & 7;
+  return (0x1230 >> (4 * ((r >> 2) & 3))) & 3;  // {0, 3, 2, 1}
+}
+
+// VEC consecutive bf16 (VEC*2 bytes, naturally aligned) -> the low VEC halves of dst[]
+template <int VEC>
+__device__ __forceinline__ void ig_load(const bf16_t* __restrict__ p, uint32_t* dst) {
+  if (VEC == 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+  } else if (VEC == 4) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    dst[0] = v.x, dst[1] = v.y;
+  }
+}
+
+struct IgRow {  // one staged pixel row: decoded once, constant over the K loop
+  int base;     // gather: pixel index of the image's first pixel; plain: element offset of the row
+  int iy0, ix0;
+  bool ok;
+};
+
+template <int FM, int FN, int BK, int VEC, int OVEC, bool GATHER>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bw,
+                                                      bf16_t* __restrict__ C, const float* __restrict__ bias,
+                                                      double* __restrict__ stats, const IGemmGeom g, int m_tiles,
+                                                      int n_tiles, int m_per_xcd) {
+  constexpr int BM = 32 * FM, BN = 32 * FN;
+  constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
+  constexpr int RPP = 256 / CPR;              // rows staged per pass of the 256 threads
+  constexpr int A_CH = BM / RPP, B_CH = (BN + RPP - 1) / RPP;  // chunks per thread per K step
+  constexpr int STAGE = (BM + BN) * BK;       // bf16 elements per LDS stage
+  constexpr int CPITCH = BN + 8;              // epilogue tile row pitch (elements): 16 bytes of padding
+  constexpr int LDS_MAIN = 2 * STAGE * 2, LDS_EPI = BM * CPITCH * 2 + 2 * BN * 4 * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[(LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI) + 64];
+  bf16_t* const lds = reinterpret_cast<bf16_t*>(lds_raw);
+  int* const tap_tab = reinterpret_cast<int*>(lds_raw + (LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI));
+
+  // XCD-aware decode: ids round-robin over the 8 XCDs; XCD x owns the contiguous M tiles [x*m_per_xcd, ...)
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int m_tile = xcd * m_per_xcd + slot / n_tiles, n_tile = slot % n_tiles;
+  if (slot / n_tiles >= m_per_xcd || m_tile >= m_tiles) return;  // whole workgroup, before any barrier
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+  if (GATHER && tid < DFINE_IGEMM_MAX_TAPS)
+    tap_tab[tid] = (g.tap_dy[tid] & 0xff) | ((g.tap_dx[tid] & 0xff) << 8) | ((g.tap_w[tid] & 0xff) << 16);
+
+  // ---- staging coordinates
+  const int st_j = tid % CPR, st_r = tid / CPR;
+  IgRow rowA[A_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int m = m0 + st_r + i * RPP;
+    rowA[i].ok = m < g.M;
+    if (GATHER) {
+      const int mm = rowA[i].ok ? m : 0;
+      const int px = mm % g.PW, t = mm / g.PW;
+      const int py = t % g.PH, b = t / g.PH;
+      rowA[i].base = b * g.IH * g.IW;
+      rowA[i].iy0 = py * g.isy;
+      rowA[i].ix0 = px * g.isx;
+    } else {
+      rowA[i].base = m * g.lda;  // host guarantees M*lda < 2^31
+      rowA[i].iy0 = rowA[i].ix0 = 0;
+    }
+  }
+  int rowB[B_CH];  // element offset of weight row n (or -1)
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {
+    const int r = st_r + i * RPP, n = n0 + r;
+    rowB[i] = (r < BN && n < g.N) ? n * g.ldb : -1;
+  }
+  if (GATHER) __syncthreads();  // tap table visible
+
+  uint32_t ra[A_CH][4], rb[B_CH][4];
+  auto fetch = [&](int step) {
+    const int kk = step * BK + st_j * 8;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) ra[i][0] = ra[i][1] = ra[i][2] = ra[i][3] = 0u;
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) rb[i][0] = rb[i][1] = rb[i][2] = rb[i][3] = 0u;
+    if (VEC == 1) {  // any alignment: element by element (D-FINE-n's 21-channel maps, the 3-channel image)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = kk + e;
+        if (k >= g.K) continue;
+        int acol = k, bcol = k, dy = 0, dx = 0;
+        if (GATHER) {
+          const int tap = k / g.CI, c = k - tap * g.CI, tt = tap_tab[tap];
+          dy = (int)(signed char)(tt & 0xff), dx = (int)(signed char)((tt >> 8) & 0xff);
+          acol = c, bcol = ((tt >> 16) & 0xff) * g.CI + c;
+        }
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+          uint32_t v = 0;
+          if (GATHER) {
+            const int iy = rowA[i].iy0 + dy, ix = rowA[i].ix0 + dx;
+            if (rowA[i].ok && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
+              v = A[(size_t)(rowA[i].base + iy * g.IW + ix) * g.lda + acol];
+          } else if (rowA[i].ok) {
+            v = A[(size_t)rowA[i].base + acol];
+          }
+          ra[i][e >> 1] |= v << (16 * (e & 1));
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+          if (rowB[i] >= 0) rb[i][e >> 1] |= (uint32_t)Bw[(size_t)rowB[i] + bcol] << (16 * (e & 1));
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 8 / VEC; ++h) {  // VEC-element groups of the chunk: a group never straddles two taps
+        const int k = kk + h * VEC;
+        if (k >= g.K) continue;
+        int acol = k, bcol = k, dy = 0, dx = 0;
+        if (GATHER) {
+          const int tap = k / g.CI, c = k - tap * g.CI, tt = tap_tab[tap];
+          dy = (int)(signed char)(tt & 0xff), dx = (int)(signed char)((tt >> 8) & 0xff);
+          acol = c, bcol = ((tt >> 16) & 0xff) * g.CI + c;
+        }
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+          if (GATHER) {
+            const int iy = rowA[i].iy0 + dy, ix = rowA[i].ix0 + dx;
+            if (rowA[i].ok && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW)
+              ig_load<VEC>(A + (size_t)(rowA[i].base + iy * g.IW + ix) * g.lda + acol, &ra[i][h * VEC / 2]);
+          } else if (rowA[i].ok) {
+            ig_load<VEC>(A + (size_t)rowA[i].base + acol, &ra[i][h * VEC / 2]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+          if (rowB[i] >= 0) ig_load<VEC>(Bw + (size_t)rowB[i] + bcol, &rb[i][h * VEC / 2]);
+      }
+    }
+  };
+  auto stage = [&](int buf) {
+    bf16_t* at = lds + buf * STAGE;
+    bf16_t* bt = at + BM * BK;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int r = st_r + i * RPP;
+      *reinterpret_cast<uint4*>(at + r * BK + ((st_j ^ ig_swz<BK>(r)) << 3)) = make_uint4(ra[i][0], ra[i][1], ra[i][2], ra[i][3]);
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int r = st_r + i * RPP;
+      if (r < BN)
+        *reinterpret_cast<uint4*>(bt + r * BK + ((st_j ^ ig_swz<BK>(r)) << 3)) = make_uint4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]);
+    }
+  };
+
+  float4v acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  const int n_steps = (g.K + BK - 1) / BK;
+  const int f_r = lane & 15, f_c = lane >> 4;
+  fetch(0);
+  stage(0);
+  if (n_steps > 1) fetch(1);
+  __syncthreads();
+  for (int s = 0; s < n_steps; ++s) {
+    const bf16_t* at = lds + (s & 1) * STAGE;
+    const bf16_t* bt = at + BM * BK;
+#pragma unroll
+    for (int sub = 0; sub < BK / 32; ++sub) {
+      short8v fw[FN], fx[FM];
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int r = wave_n * (BN / 2) + 16 * i + f_r;
+        fw[i] = *reinterpret_cast<const short8v*>(bt + r * BK + (((sub * 4 + f_c) ^ ig_swz<BK>(r)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int r = wave_m * (BM / 2) + 16 * j + f_r;
+        fx[j] = *reinterpret_cast<const short8v*>(at + r * BK + (((sub * 4 + f_c) ^ ig_swz<BK>(r)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < n_steps) {
+      stage((s + 1) & 1);  // stage (s+1)&1 held step s-1: every wave finished reading it before the last barrier
+      if (s + 2 < n_steps) fetch(s + 2);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators (+bias, act) -> bf16 tile in LDS -> coalesced rows (+ per-channel statistics)
+  // D layout of mfma_f32_16x16x32 with the weight tile as operand A: row (= n) = (lane>>4)*4 + reg, col (= m) = lane&15
+  bf16_t* ct = lds;
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+    const int nl = wave_n * (BN / 2) + 16 * i + 4 * f_c;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n0 + nl + e < g.N) bv[e] = bias[n0 + nl + e];
+    }
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      const int ml = wave_m * (BM / 2) + 16 * j + f_r;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = acc[i][j][e] + bv[e];
+        if (g.act == 1) v[e] = fmaxf(v[e], 0.f);
+      }
+      uint2 pk;
+      pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+      pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+      *reinterpret_cast<uint2*>(ct + ml * CPITCH + nl) = pk;
+    }
+  }
+  __syncthreads();
+  constexpr int OCPR = BN / 8, ORPP = 256 / OCPR;  // 16-byte chunks per output row, rows per pass
+  const int o_j = tid % OCPR, o_r = tid / OCPR;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  const int ncol = n0 + o_j * 8;
+  const int nvalid = min(max(g.N - ncol, 0), 8);
+#pragma unroll
+  for (int i = 0; i < BM / ORPP; ++i) {
+    const int ml = o_r + i * ORPP, m = m0 + ml;
+    if (m >= g.M || nvalid == 0) continue;
+    const uint4 v = *reinterpret_cast<const uint4*>(ct + ml * CPITCH + o_j * 8);
+    size_t orow;
+    if (GATHER) {
+      const int px = m % g.PW, t = m / g.PW;
+      const int py = t % g.PH, b = t / g.PH;
+      orow = ((size_t)(b * g.OHf + py * g.osy + g.ooy) * g.OWf + px * g.osx + g.oox) * g.ldc;
+    } else {
+      orow = (size_t)m * g.ldc;
+    }
+    bf16_t* dst = C + orow + ncol;
+    if (OVEC == 8 && nvalid == 8) {
+      *reinterpret_cast<uint4*>(dst) = v;
+    } else {
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (e < nvalid) dst[e] = (bf16_t)(w[e >> 1] >> (16 * (e & 1)));
+    }
+    if (stats != nullptr) {
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = __uint_as_float((w[e >> 1] >> (16 * (e & 1))) << 16);
+        s1[e] += f;
+        s2[e] += f * f;
+      }
+    }
+  }
+  if (stats != nullptr) {
+    // threads with the same chunk column: lanes o_j + k*OCPR of every wave -> shuffle within the wave, LDS across waves
+    float* red = reinterpret_cast<float*>(lds_raw + BM * CPITCH * 2);  // [2][BN] after the C tile
+    if (tid < 2 * BN) red[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = s1[e], b = s2[e];
+#pragma unroll
+      for (int d = OCPR; d < 64; d <<= 1) {
+        a += __shfl_xor(a, d, 64);
+        b += __shfl_xor(b, d, 64);
+      }
+      if (lane < OCPR) {
+        atomicAdd(red + o_j * 8 + e, a);
+        atomicAdd(red + BN + o_j * 8 + e, b);
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int q = tid / BN, c = tid % BN;
+      if (n0 + c < g.N) atomicAdd(stats + ((size_t)(blockIdx.x & 7) * 2 + q) * g.N + n0 + c, (double)red[tid]);
+    }
+  }
+}
+
+static inline int ig_tile_n(int N) {
+  // the widest tile whose padding waste is not worse than a narrower one's (A is re-read once per N tile)
+  int best = 128, best_pad = (N + 127) / 128 * 128;
+  const int cands[2] = {64, 32};
+  for (int c : cands) {
+    const int pad = (N + c - 1) / c * c;
+    if (pad < best_pad) best = c, best_pad = pad;
+  }
+  return best;
+}
+
+template <int FN, int BK, int VEC, int OVEC, bool GATHER>
+static int ig_launch(const void* A, const void* Bw, void* C, const float* bias, double* stats, const IGemmGeom& g,
+                     hipStream_t stream) {
+  constexpr int BM = 128, BN = 32 * FN;
+  const int m_tiles = (g.M + BM - 1) / BM, n_tiles = (g.N + BN - 1) / BN;
+  const int m_per_xcd = (m_tiles + 7) / 8;
+  const long long grid = 8LL * m_per_xcd * n_tiles;
+  if (grid > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
+  hipLaunchKernelGGL((igemm_kernel<4, FN, BK, VEC, OVEC, GATHER>), dim3((unsigned)grid), dim3(256), 0, stream,
+                     (const bf16_t*)A, (const bf16_t*)Bw, (bf16_t*)C, bias, stats, g, m_tiles, n_tiles, m_per_xcd);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int BK, int VEC, int OVEC, bool GATHER>
+static int ig_dispatch_n(const void* A, const void* Bw, void* C, const float* bias, double* stats, const IGemmGeom& g,
+                         hipStream_t stream) {
+  switch (ig_tile_n(g.N)) {
+    case 128: return ig_launch<4, BK, VEC, OVEC, GATHER>(A, Bw, C, bias, stats, g, stream);
+    case 64: return ig_launch<2, BK, VEC, OVEC, GATHER>(A, Bw, C, bias, stats, g, stream);
+    default: return ig_launch<1, BK, VEC, OVEC, GATHER>(A, Bw, C, bias, stats, g, stream);
+  }
+}
+
+template <int VEC, int OVEC, bool GATHER>
+static int ig_dispatch_k(const void* A, const void* Bw, void* C, const float* bias, double* stats, const IGemmGeom& g,
+                         hipStream_t stream) {
+  // BK = 64 halves the barriers per MFMA; BK = 32 wastes less on a K that is not a multiple of 64
+  const int pad64 = (g.K + 63) / 64 * 64, pad32 = (g.K + 31) / 32 * 32;
+  if (pad64 == pad32 || g.K >= 1024) return ig_dispatch_n<64, VEC, OVEC, GATHER>(A, Bw, C, bias, stats, g, stream);
+  return ig_dispatch_n<32, VEC, OVEC, GATHER>(A, Bw, C, bias, stats, g, stream);
+}
+
+template <int VEC, int OVEC>
+static int ig_dispatch_g(const void* A, const void* Bw, void* C, const float* bias, double* stats, const IGemmGeom& g,
+                         hipStream_t stream) {
+  return g.gather ? ig_dispatch_k<VEC, OVEC, true>(A, Bw, C, bias, stats, g, stream)
+                  : ig_dispatch_k<VEC, OVEC, false>(A, Bw, C, bias, stats, g, stream);
+}
+
+}  // namespace dfine
+
+using namespace dfine;
+
+extern "C" int dfine_igemm_bf16(const void* A, const void* Bw, void* C, const float* bias, double* stats,
+                                const dfine_igemm_geom* geom, void* stream) {
+  if (!A || !Bw || !C || !geom) return DFINE_E_BADARG;
+  const IGemmGeom& g = *geom;
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.lda <= 0 || g.ldb < 0 || g.ldc < g.N) return DFINE_E_BADARG;
+  if (g.act != 0 && g.act != 1) return DFINE_E_BADARG;
+  long long a_extent;  // elements addressed in A (pixel offsets are 32-bit in the kernel)
+  if (g.gather) {
+    if (g.PH <= 0 || g.PW <= 0 || g.IH <= 0 || g.IW <= 0 || g.CI <= 0 || g.ntaps <= 0 || g.ntaps > DFINE_IGEMM_MAX_TAPS)
+      return DFINE_E_BADARG;
+    if (g.K != g.ntaps * g.CI || g.M % (g.PH * g.PW) != 0 || g.lda < g.CI) return DFINE_E_BADARG;
+    if (g.isy <= 0 || g.isx <= 0 || g.osy <= 0 || g.osx <= 0 || g.ooy < 0 || g.oox < 0) return DFINE_E_BADARG;
+    // the output pixels this launch writes must lie inside the [OHf, OWf] map
+    if ((g.PH - 1) * g.osy + g.ooy >= g.OHf || (g.PW - 1) * g.osx + g.oox >= g.OWf) return DFINE_E_BADARG;
+    int max_w = 0;
+    for (int t = 0; t < g.ntaps; ++t) {
+      if (g.tap_w[t] < 0) return DFINE_E_BADARG;
+      if (g.tap_w[t] > max_w) max_w = g.tap_w[t];
+    }
+    if (g.ldb < (max_w + 1) * g.CI) return DFINE_E_BADARG;
+    const long long images = g.M / ((long long)g.PH * g.PW);
+    a_extent = images * g.IH * g.IW * g.lda;
+    if (images * g.OHf * g.OWf * (long long)g.ldc > 0x7fffffffLL * 64) return DFINE_E_UNSUPPORTED;
+  } else {
+    if (g.lda < g.K || g.ldb < g.K) return DFINE_E_BADARG;
+    a_extent = (long long)g.M * g.lda;
+  }
+  if (a_extent > 0x7fffffffLL || (long long)g.N * g.ldb > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
+  // widest access every row start and tap offset is aligned for
+  const uintptr_t pa = (uintptr_t)A, pb = (uintptr_t)Bw, pc = (uintptr_t)C;
+  const int unit = g.gather ? g.CI : g.K;  // granularity at which A/B columns start
+  int vec = 1;
+  if (unit % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && pa % 16 == 0 && pb % 16 == 0) vec = 8;
+  else if (unit % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && pa % 8 == 0 && pb % 8 == 0) vec = 4;
+  const bool ovec8 = g.ldc % 8 == 0 && pc % 16 == 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (vec == 8) return ovec8 ? ig_dispatch_g<8, 8>(A, Bw, C, bias, stats, g, st) : ig_dispatch_g<8, 1>(A, Bw, C, bias, stats, g, st);
+  if (vec == 4) return ovec8 ? ig_dispatch_g<4, 8>(A, Bw, C, bias, stats, g, st) : ig_dispatch_g<4, 1>(A, Bw, C, bias, stats, g, st);
+  return ovec8 ? ig_dispatch_g<1, 8>(A, Bw, C, bias, stats, g, st) : ig_dispatch_g<1, 1>(A, Bw, C, bias, stats, g, st);
+}

@@ -1,0 +1,82 @@
+// Two small kernels around the parameters:
+//   * dfine_transpose_weights: bf16 [K][T][C] -> [C][T][K] for every weight of the model in one launch --
+//     the "transposed shadow" the input-gradient GEMMs read (dx = dy W needs W with the output channel as
+//     the contiguous reduction axis; the forward wants the input channel contiguous). Refreshed once per
+//     optimizer step over the whole flat bf16 shadow: ~2 x 40 MB of traffic for D-FINE-m.
+//   * dfine_embedding_wgrad: dW[idx[m]] += g[m] (nn.Embedding backward for the denoising class embedding,
+//     reference dfine_decoder.py:434 / arch/utils.py:434) as float atomics into the flat fp32 gradient.
+#include "common.h"
+
+namespace dfine {
+
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                               const long long* __restrict__ table,
+                                                               const int* __restrict__ blocks) {
+  __shared__ bf16_t tile[32][33];
+  const int w = blocks[2 * blockIdx.x], t_idx = blocks[2 * blockIdx.x + 1];
+  const long long* e = table + 5 * (long long)w;
+  const long long so = e[0], dof = e[1];
+  const int K = (int)e[2], T = (int)e[3], C = (int)e[4];
+  const int kt = (K + 31) / 32, ct = (C + 31) / 32;
+  const int t = t_idx / (kt * ct), rem = t_idx % (kt * ct);
+  const int k0 = (rem / ct) * 32, c0 = (rem % ct) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + ty + 8 * i, c = c0 + tx;
+    if (k < K && c < C) tile[ty + 8 * i][tx] = src[so + ((long long)k * T + t) * C + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, k = k0 + tx;
+    if (k < K && c < C) dst[dof + ((long long)c * T + t) * K + k] = tile[tx][ty + 8 * i];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_wgrad_kernel(const long long* __restrict__ idx, const T* __restrict__ g,
+                                                             float* __restrict__ dW, long long M, int D, int rows,
+                                                             int padding_idx) {
+  // one wave per row m (grid-stride): each wave instruction adds 64 consecutive floats of one dW row
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long n_waves = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long m = wave; m < M; m += n_waves) {
+    const long long r = idx[m];
+    if (r < 0 || r >= rows || r == padding_idx) continue;
+    for (int c = lane; c < D; c += 64) atomicAdd(dW + r * D + c, VecTraits<T>::load1(g + m * D + c));
+  }
+}
+
+}  // namespace dfine
+
+using namespace dfine;
+
+extern "C" int dfine_transpose_weights(const void* src, void* dst, const long long* table, const int* blocks,
+                                       int n_blocks, void* stream) {
+  if (!src || !dst || !table || !blocks) return DFINE_E_BADARG;
+  if (n_blocks <= 0) return DFINE_E_BADARG;
+  hipLaunchKernelGGL(transpose_weights_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                     (bf16_t*)dst, table, blocks);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dfine_embedding_wgrad(const long long* idx, const void* g, int dtype, float* dW, long long M, int D,
+                                     int rows, int padding_idx, void* stream) {
+  if (!idx || !g || !dW) return DFINE_E_BADARG;
+  if (M <= 0 || D <= 0 || rows <= 0) return DFINE_E_BADARG;
+  long long blocks = (M + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == DFINE_DT_F32)
+    hipLaunchKernelGGL(embedding_wgrad_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, idx,
+                       (const float*)g, dW, M, D, rows, padding_idx);
+  else if (dtype == DFINE_DT_BF16)
+    hipLaunchKernelGGL(embedding_wgrad_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, idx,
+                       (const bf16_t*)g, dW, M, D, rows, padding_idx);
+  else
+    return DFINE_E_UNSUPPORTED;
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}

@@ -304,6 +304,66 @@ int dfine_add_layernorm_bwd(const void* dy, const void* s, int dtype, const floa
                             const float* rstd, void* ds, float* dgamma, float* dbeta, long long M, int D, float clamp,
                             void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / Linear, forward and input gradient, bf16 MFMA with fp32 accumulation:
+ *     C[m][n] = act( sum_k A(m, k) * Bw[n][k] + bias[n] )
+ * Replaces the ATen/MIOpen `convolution` + `convolution_backward(input)` behind every dense nn.Conv2d of
+ * the path (ConvBNAct, reference src/d_fine/arch/hgnetv2.py:35-80; ConvNormLayer_fuse / VGGBlock / CSPLayer /
+ * RepNCSPELAN4 / SCDown.cv1, hybrid_encoder.py:21-45,106-121,182-239; MaskPixelDecoder incl. its
+ * ConvTranspose2d, dfine_decoder.py:316-376) and the `addmm`/`mm` behind every nn.Linear forward and input
+ * gradient (MLP dfine_decoder.py:33-46, MSDeformableAttention projections :119-178, decoder layer
+ * :233-271, AIFI hybrid_encoder.py:243-290).
+ *
+ * gather == 0 ("plain"): A(m, k) = A[m*lda + k]; output row m at C + m*ldc.
+ * gather == 1: rows are the pixels of a [images, PH, PW] grid, m = (b*PH + py)*PW + px; K = ntaps*CI and
+ *     A(m, tap*CI + c) = A[((b*IH + py*isy + tap_dy[tap])*IW + px*isx + tap_dx[tap])*lda + c]   (0 outside the map)
+ *     Bw column of (tap, c) = tap_w[tap]*CI + c                                               (row pitch ldb)
+ *     output row m at C + ((b*OHf + py*osy + ooy)*OWf + px*osx + oox)*ldc
+ *   conv forward (stride s, padding p): taps (ky, kx) -> dy = ky - p, dx = kx - p, tap_w = ky*KW + kx, isy = isx = s,
+ *   Bw = the channels_last weight [CO][KH][KW][CI]; input gradient of a stride-1 conv: dy = p - ky, same tap_w, Bw =
+ *   [CI][KH][KW][CO] (dfine_transpose_weights); a strided conv's input gradient is one launch per parity class of input
+ *   pixels (osy/ooy select the class, only the taps of that class are listed); transposed 2x2 stride-2 conv: four
+ *   1-tap launches with osy = osx = 2 and (ooy, oox) = the tap.
+ *   A, Bw, C bf16; bias f32 [N] or NULL; act 0 = none, 1 = ReLU.
+ *   stats (or NULL): f64 [8][2][N], ACCUMULATED: per output channel the sum and the sum of squares of the bf16-rounded
+ *   outputs, spread over 8 replicas -- the layout dfine_bn_act_fwd reads, so a BatchNorm after the conv skips its
+ *   statistics pass. Any alignment is accepted (16-byte vector path when CI (gather) / K (plain), lda, ldb are
+ *   multiples of 8 and the bases are 16-byte aligned; 8-byte and element-wise paths otherwise).
+ * ------------------------------------------------------------------------------------- */
+#define DFINE_IGEMM_MAX_TAPS 16
+typedef struct dfine_igemm_geom {
+  int M, N, K;
+  int lda, ldb, ldc;
+  int gather;
+  int PH, PW, IH, IW, CI, ntaps, isy, isx;
+  int OHf, OWf, osy, osx, ooy, oox;
+  int act;
+  signed char tap_dy[DFINE_IGEMM_MAX_TAPS], tap_dx[DFINE_IGEMM_MAX_TAPS], tap_w[DFINE_IGEMM_MAX_TAPS];
+} dfine_igemm_geom;
+int dfine_igemm_bf16(const void* A, const void* Bw, void* C, const float* bias, double* stats,
+                     const dfine_igemm_geom* geom /* host */, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Transposed bf16 copies of weights for the input-gradient GEMMs: for each of n weights
+ *     dst[c][t][k] = src[k][t][c]      (src [K][T][C] -> dst [C][T][K]; a Linear weight has T = 1)
+ * in ONE launch (the optimizer step refreshes every weight's transposed shadow after the update;
+ * reference: what autograd's mm(grad, weight) / convolution_backward read implicitly).
+ *   table: int64 [n][5] device = (src element offset, dst element offset, K, T, C); blocks: int32 [n_blocks][2]
+ *   device = (weight index, tile index) for every 32x32 tile (tile index runs over T * ceil(K/32) * ceil(C/32)).
+ * ------------------------------------------------------------------------------------- */
+int dfine_transpose_weights(const void* src /* bf16 */, void* dst /* bf16 */, const long long* table,
+                            const int* blocks, int n_blocks, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Weight gradient of nn.Embedding (the denoising class embedding, reference dfine_decoder.py:434 via
+ * arch/utils.py:357-467): dW[idx[m]][:] += g[m][:] for idx[m] != padding_idx, as fp32 atomics straight into
+ * the (flat) fp32 gradient. Replaces ATen's embedding_dense_backward (a sort + unique-by-key + segment pipeline
+ * of ~10 launches whose scratch is sized by data read back from the device).
+ *   idx int64 [M], g bf16 or f32 (dtype) [M, D], dW f32 [rows, D] ACCUMULATED; indices outside [0, rows) are skipped.
+ * ------------------------------------------------------------------------------------- */
+int dfine_embedding_wgrad(const long long* idx, const void* g, int dtype, float* dW, long long M, int D, int rows,
+                          int padding_idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
