@@ -17,17 +17,17 @@ class Stem(nn.Module):
         self.stem1 = ConvNorm(c_in, c_mid, 3, stride=2, **kw)
         self.stem2a = ConvNorm(c_mid, c_mid // 2, 2, **kw)
         self.stem2b = ConvNorm(c_mid // 2, c_mid, 2, **kw)
+        self.stem2a.pad_br = self.stem2b.pad_br = 1  # F.pad(x, (0, 1, 0, 1)) folded into the conv's tap bounds
         self.stem3 = ConvNorm(c_mid * 2, c_mid, 3, stride=2, **kw)
         self.stem4 = ConvNorm(c_mid, c_out, 1, **kw)
 
     def forward(self, x):
         u = self.stem1(x)
-        x = F.pad(u, (0, 1, 0, 1))  # right/bottom pad so the 2x2 convs keep H, W
-        branch = self.stem2b(F.pad(self.stem2a(x), (0, 1, 0, 1)))
+        branch = self.stem2b(self.stem2a(u))  # 2x2 convs on the map zero-extended by one row / column (no padded copy)
         if ops.stem_pool_supported(u):
             pooled = ops.stem_pool(u)  # HIP: max-pool of the zero-extended map, no padded copy
         else:
-            pooled = F.max_pool2d(x, 2, stride=1, ceil_mode=True)
+            pooled = F.max_pool2d(F.pad(u, (0, 1, 0, 1)), 2, stride=1, ceil_mode=True)
         return self.stem4(self.stem3(torch.cat([pooled, branch], 1)))
 
 

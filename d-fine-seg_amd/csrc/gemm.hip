@@ -65,7 +65,7 @@ struct __attribute__((packed, aligned(4))) Vec16u {
 template <bool EDGE>
 __device__ __forceinline__ Vec16 load_chunk(const bf16_t* __restrict__ p, int valid) {
   Vec16 v;
-  if (!EDGE || valid == 8) {
+  if (!EDGE || (valid == 8 && (reinterpret_cast<uintptr_t>(p) & 3) == 0)) {
     const Vec16u u = *reinterpret_cast<const Vec16u*>(p);
     v.w[0] = u.w[0], v.w[1] = u.w[1], v.w[2] = u.w[2], v.w[3] = u.w[3];
   } else {
@@ -80,6 +80,7 @@ __device__ __forceinline__ Vec16 load_chunk(const bf16_t* __restrict__ p, int va
 
 struct ConvGeom {
   int H, W, CI, OH, OW, KW, stride, pad;
+  int ldy, ldx;  // row pitch (elements) of dY rows / X pixels (>= N / CI: channel slices of wider maps)
 };
 
 // pixel cursor of one staged row: advances by WG_MSTEP output pixels per step without dividing
@@ -100,7 +101,10 @@ struct PixelCursor {
   }
 };
 
-template <int TN, int TK, bool CONV, int DEPTH, bool EDGE>
+// EDGE: dY rows / N not 16-byte friendly (element-wise loads where a chunk is partial or misaligned).
+// XVEC: widest aligned load of X: 8 = a 16-byte chunk is 8 channels of ONE tap (CI % 8 == 0) resp. 8 columns of a Linear
+// row; 4 / 1 = a chunk is assembled from 8-byte / 2-byte pieces that may belong to different taps (CI = 12, 3, 21, ...).
+template <int TN, int TK, bool CONV, int DEPTH, bool EDGE, int XVEC>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
                                                     float* __restrict__ dW, float* __restrict__ db, int M, int N,
                                                     int K, int ldw, int m_chunk, int n_chunks, int k_tiles,
@@ -132,6 +136,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict_
   // row may be partial; rows are then only 4-byte aligned, which a global dwordx4 load does not mind)
   const int a_valid = min(max(N - (n0 + a_j * 8), 0), 8), b_valid = min(max(K - (k0 + b_j * 8), 0), 8);
   int tap_dy = 0, tap_dx = 0, chan = 0;
+  // EDGE conv builds (CI % 8 != 0: the 3-channel image, 12 / 21-channel maps): a chunk's 8 columns can belong to
+  // different taps, so every element carries its own (tap offset, channel)
+  constexpr int NE = (CONV && XVEC < 8) ? 8 / XVEC : 1;  // pieces per chunk
+  int e_dy[NE], e_dx[NE], e_ch[NE];
   PixelCursor cur_px[B_ROWS];
   if (CONV) {
     const int kk = k0 + b_j * 8;
@@ -139,6 +147,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict_
     chan = kk % geom.CI;
     tap_dy = tap / geom.KW - geom.pad;
     tap_dx = tap % geom.KW - geom.pad;
+    if (XVEC < 8) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int k = kk + e * XVEC, t = k / geom.CI;
+        e_ch[e] = k < K ? k % geom.CI : -1;
+        e_dy[e] = t / geom.KW - geom.pad;
+        e_dx[e] = t % geom.KW - geom.pad;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) cur_px[i].init((long long)m_begin + b_r + i * B_RSTEP, geom);
   }
@@ -161,19 +178,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict_
     for (int i = 0; i < A_ROWS; ++i) {
       const int m = m0 + a_r + i * A_RSTEP;
       va[slot][i].w[0] = va[slot][i].w[1] = va[slot][i].w[2] = va[slot][i].w[3] = 0u;
-      if (m < m_end && a_valid > 0) va[slot][i] = load_chunk<EDGE>(dY + (size_t)m * N + n0 + a_j * 8, a_valid);
+      if (m < m_end && a_valid > 0) va[slot][i] = load_chunk<EDGE>(dY + (size_t)m * geom.ldy + n0 + a_j * 8, a_valid);
     }
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) {
       const int m = m0 + b_r + i * B_RSTEP;
       vb[slot][i].w[0] = vb[slot][i].w[1] = vb[slot][i].w[2] = vb[slot][i].w[3] = 0u;
-      if (CONV) {
+      if (CONV && XVEC < 8) {
+        if (m < m_end && b_valid > 0) {
+          const int oy = cur_px[i].oy * geom.stride, ox = cur_px[i].ox * geom.stride;
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            const int iy = oy + e_dy[e], ix = ox + e_dx[e];
+            if (e_ch[e] >= 0 && (unsigned)iy < (unsigned)geom.H && (unsigned)ix < (unsigned)geom.W) {
+              const bf16_t* src = X + (((size_t)cur_px[i].b * geom.H + iy) * geom.W + ix) * geom.ldx + e_ch[e];
+              if (XVEC == 4) {
+                const uint2 v = *reinterpret_cast<const uint2*>(src);
+                vb[slot][i].w[2 * e] = v.x, vb[slot][i].w[2 * e + 1] = v.y;
+              } else {
+                vb[slot][i].w[e >> 1] |= (uint32_t)(*src) << (16 * (e & 1));
+              }
+            }
+          }
+        }
+        cur_px[i].advance(geom);
+      } else if (CONV) {
         const int iy = cur_px[i].oy * geom.stride + tap_dy, ix = cur_px[i].ox * geom.stride + tap_dx;
         if (m < m_end && b_valid > 0 && (unsigned)iy < (unsigned)geom.H && (unsigned)ix < (unsigned)geom.W)
-          vb[slot][i] = load_chunk<false>(X + (((size_t)cur_px[i].b * geom.H + iy) * geom.W + ix) * geom.CI + chan, 8);
+          vb[slot][i] = load_chunk<false>(X + (((size_t)cur_px[i].b * geom.H + iy) * geom.W + ix) * geom.ldx + chan, 8);
         cur_px[i].advance(geom);
       } else {
-        if (m < m_end && b_valid > 0) vb[slot][i] = load_chunk<EDGE>(X + (size_t)m * K + k0 + b_j * 8, b_valid);
+        if (m < m_end && b_valid > 0) vb[slot][i] = load_chunk<(XVEC < 8)>(X + (size_t)m * geom.ldx + k0 + b_j * 8, b_valid);
       }
     }
   };
@@ -267,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict_
 // a 128-wide tile only where it wastes no more padding than 64-wide tiles do
 static inline int tile_width(int n) { return ((n + 127) / 128 * 128 == (n + 63) / 64 * 64) ? 128 : 64; }
 
-template <bool CONV, int DEPTH, bool EDGE>
+template <bool CONV, int DEPTH, bool EDGE, int XVEC>
 static int launch_wgrad(const void* dY, const void* X, float* dW, float* db, int M, int N, int K, int ldw,
                         const ConvGeom& geom, hipStream_t stream) {
   // Split of the M axis: all workgroups do the same amount of work, so their number should fill the
@@ -301,7 +336,7 @@ static int launch_wgrad(const void* dY, const void* X, float* dW, float* db, int
   const long long grid = (n_chunks + 7) / 8 * 8 * tiles;
   if (grid > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
 #define DFINE_WGRAD_LAUNCH(TN_, TK_)                                                                          \
-  hipLaunchKernelGGL((wgrad_kernel<TN_, TK_, CONV, DEPTH, EDGE>), dim3((unsigned)grid), dim3(256), 0, stream,              \
+  hipLaunchKernelGGL((wgrad_kernel<TN_, TK_, CONV, DEPTH, EDGE, XVEC>), dim3((unsigned)grid), dim3(256), 0, stream,        \
                      (const bf16_t*)dY, (const bf16_t*)X, dW, db, M, N, K, ldw, (int)m_chunk, (int)n_chunks, \
                      k_tiles, (int)tiles, geom)
   if (tn == 128 && tk == 128) DFINE_WGRAD_LAUNCH(128, 128);
@@ -317,49 +352,48 @@ static int launch_wgrad(const void* dY, const void* X, float* dW, float* db, int
 
 using namespace dfine;
 
-// prefetch depth (ring slots); DFINE_WGRAD_DEPTH=2 selects the shallow build for A/B measurements
-static int wgrad_depth() {
-  static const int depth = [] {
-    const char* e = getenv("DFINE_WGRAD_DEPTH");
-    return (e && atoi(e) == 2) ? 2 : 4;
-  }();
-  return depth;
-}
-
-// EDGE builds carry the element-wise path for a partial last chunk (N or K not a multiple of 8)
+// `edge`: dY side (N, ldy, base) not 16-byte friendly; `xvec`: widest aligned piece of an X chunk (8, 4 or 1 elements)
 template <bool CONV>
 static int dispatch_wgrad(const void* dY, const void* X, float* dW, float* db, int M, int N, int K, int ldw,
-                          const ConvGeom& geom, hipStream_t stream) {
-  const bool edge = N % 8 != 0 || K % 8 != 0;
-  if (wgrad_depth() == 2)
-    return edge ? launch_wgrad<CONV, 2, true>(dY, X, dW, db, M, N, K, ldw, geom, stream)
-                : launch_wgrad<CONV, 2, false>(dY, X, dW, db, M, N, K, ldw, geom, stream);
-  return edge ? launch_wgrad<CONV, 4, true>(dY, X, dW, db, M, N, K, ldw, geom, stream)
-              : launch_wgrad<CONV, 4, false>(dY, X, dW, db, M, N, K, ldw, geom, stream);
+                          const ConvGeom& geom, bool edge, int xvec, hipStream_t stream) {
+  if (xvec == 8)
+    return edge ? launch_wgrad<CONV, 4, true, 8>(dY, X, dW, db, M, N, K, ldw, geom, stream)
+                : launch_wgrad<CONV, 4, false, 8>(dY, X, dW, db, M, N, K, ldw, geom, stream);
+  if (CONV && xvec == 4)
+    return edge ? launch_wgrad<CONV, 4, true, CONV ? 4 : 1>(dY, X, dW, db, M, N, K, ldw, geom, stream)
+                : launch_wgrad<CONV, 4, false, CONV ? 4 : 1>(dY, X, dW, db, M, N, K, ldw, geom, stream);
+  return edge ? launch_wgrad<CONV, 4, true, 1>(dY, X, dW, db, M, N, K, ldw, geom, stream)
+              : launch_wgrad<CONV, 4, false, 1>(dY, X, dW, db, M, N, K, ldw, geom, stream);
 }
 
 extern "C" int dfine_linear_wgrad(const void* dY, const void* X, float* dW, float* db, int M, int N, int K,
-                                  int ldw, void* stream) {
+                                  int ldw, int ldy, int ldx, void* stream) {
   if (!dY || !X || !dW) return DFINE_E_BADARG;
-  if (M <= 0 || N <= 0 || K <= 0 || ldw < K) return DFINE_E_BADARG;
-  if (N % 2 != 0 || K % 2 != 0) return DFINE_E_UNSUPPORTED;  // rows must stay 4-byte aligned
-  return dispatch_wgrad<false>(dY, X, dW, db, M, N, K, ldw, ConvGeom{}, (hipStream_t)stream);
+  if (M <= 0 || N <= 0 || K <= 0 || ldw < K || ldy < N || ldx < K) return DFINE_E_BADARG;
+  ConvGeom geom{};
+  geom.ldy = ldy, geom.ldx = ldx;
+  const bool edge = !(N % 8 == 0 && ldy % 8 == 0 && (uintptr_t)dY % 16 == 0);
+  const int xvec = (K % 8 == 0 && ldx % 8 == 0 && (uintptr_t)X % 16 == 0) ? 8 : 1;
+  return dispatch_wgrad<false>(dY, X, dW, db, M, N, K, ldw, geom, edge, xvec, (hipStream_t)stream);
 }
 
 extern "C" int dfine_conv_wgrad(const void* dY, const void* X, float* dW, int B, int H, int W, int CI, int OH,
-                                int OW, int CO, int KH, int KW, int stride, int pad, void* stream) {
+                                int OW, int CO, int KH, int KW, int stride, int pad, int ldy, int ldx, void* stream) {
   if (!dY || !X || !dW) return DFINE_E_BADARG;
   if (B <= 0 || H <= 0 || W <= 0 || CI <= 0 || OH <= 0 || OW <= 0 || CO <= 0 || KH <= 0 || KW <= 0 || stride <= 0 ||
-      pad < 0)
+      pad < 0 || ldy < CO || ldx < CI)
     return DFINE_E_BADARG;
-  if (H + 2 * pad < KH || W + 2 * pad < KW || OH != (H + 2 * pad - KH) / stride + 1 || OW != (W + 2 * pad - KW) / stride + 1)
-    return DFINE_E_BADARG;  // output extent inconsistent with the input extent
-  if (CI % 8 != 0 || CO % 2 != 0) return DFINE_E_UNSUPPORTED;  // an 8-column chunk must not straddle two taps
+  // the last output's first tap must start inside the (top/left padded) input: bottom/right padding is implied by OH/OW
+  if ((OH - 1) * stride - pad >= H || (OW - 1) * stride - pad >= W) return DFINE_E_BADARG;
   const long long M = (long long)B * OH * OW;
-  if (M > 0x7fffffffLL - 64) return DFINE_E_UNSUPPORTED;
-  const ConvGeom geom{H, W, CI, OH, OW, KW, stride, pad};
+  if (M > 0x7fffffffLL - 64 || (long long)B * H * W * ldx > 0x7fffffffffLL) return DFINE_E_UNSUPPORTED;
+  ConvGeom geom{H, W, CI, OH, OW, KW, stride, pad, ldy, ldx};
   const int K = KH * KW * CI;
-  if (KH == 1 && KW == 1 && stride == 1 && pad == 0)  // rows are not gathered: the Linear path
-    return dispatch_wgrad<false>(dY, X, dW, nullptr, (int)M, CO, K, K, geom, (hipStream_t)stream);
-  return dispatch_wgrad<true>(dY, X, dW, nullptr, (int)M, CO, K, K, geom, (hipStream_t)stream);
+  const bool edge = !(CO % 8 == 0 && ldy % 8 == 0 && (uintptr_t)dY % 16 == 0);
+  int xvec = 1;
+  if (CI % 8 == 0 && ldx % 8 == 0 && (uintptr_t)X % 16 == 0) xvec = 8;
+  else if (CI % 4 == 0 && ldx % 4 == 0 && (uintptr_t)X % 8 == 0) xvec = 4;
+  if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && OH == H && OW == W)  // rows are not gathered: the Linear path
+    return dispatch_wgrad<false>(dY, X, dW, nullptr, (int)M, CO, K, K, geom, edge, xvec == 8 ? 8 : 1, (hipStream_t)stream);
+  return dispatch_wgrad<true>(dY, X, dW, nullptr, (int)M, CO, K, K, geom, edge, xvec, (hipStream_t)stream);
 }

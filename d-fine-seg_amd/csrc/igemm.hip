@@ -327,12 +327,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const bf16_t* __restrict_
 }
 
 static inline int ig_tile_n(int N) {
-  // the widest tile whose padding waste is not worse than a narrower one's (A is re-read once per N tile)
-  int best = 128, best_pad = (N + 127) / 128 * 128;
+  // cost of a tile width = padded columns (wasted MFMA work) + 16 per N tile (A is re-read once per tile); ties go to
+  // the wider tile
+  int best = 128, best_cost = (N + 127) / 128 * 128 + 16 * ((N + 127) / 128);
   const int cands[2] = {64, 32};
   for (int c : cands) {
-    const int pad = (N + c - 1) / c * c;
-    if (pad < best_pad) best = c, best_pad = pad;
+    const int tiles = (N + c - 1) / c, cost = tiles * c + 16 * tiles;
+    if (cost < best_cost) best = c, best_cost = cost;
   }
   return best;
 }

@@ -172,13 +172,29 @@ class MaskPixelDecoder(nn.Module):
         self.upconv = nn.ConvTranspose2d(out_ch, out_ch, 2, stride=2, bias=False)
         self.bn1 = nn.BatchNorm2d(out_ch)
 
+    def _conv_bn(self, conv, bn, x, act=None, addend=None, transposed=False):
+        """conv -> BatchNorm (+addend) (+act) through the HIP kernels (implicit-GEMM conv with the statistics in its
+        epilogue, fused norm); parameters stay in the reference's nn.Conv2d / nn.BatchNorm2d modules (state_dict keys)."""
+        if not (x.is_cuda and ops.batch_norm_act_supported(x, conv.out_channels)):
+            y = bn(conv(x))
+            y = y + addend if addend is not None else y
+            return F.relu(y) if act == "relu" else y
+        bf16_mode = torch.is_autocast_enabled() or x.dtype == torch.bfloat16
+        ws = ops.bn_workspace(conv.out_channels, x.device) if (bf16_mode and self.training) else None
+        stats = ws[: 32 * conv.out_channels] if ws is not None else None
+        y = ops.conv_transpose2x2(x, conv.weight, stats) if transposed else ops.dense_conv(x, conv.weight, 1, 0, stats=stats)
+        if self.training:
+            bn.num_batches_tracked.add_(1)
+        return ops.batch_norm_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, act, addend=addend,
+                                  training=self.training, momentum=bn.momentum or 0.1, eps=bn.eps, ws=ws, have_stats=ws is not None)
+
     def forward(self, feats, enc_s8):
-        x = self.bn[0](self.lateral[0](feats[0]))
+        x = self._conv_bn(self.lateral[0], self.bn[0], feats[0])
         size = x.shape[-2:]
         for i in range(1, len(feats)):
-            x = x + F.interpolate(self.bn[i](self.lateral[i](feats[i])), size=size, mode="bilinear", align_corners=False)
-        x = x + self.enc_bn(self.enc_proj(enc_s8))  # same size: the reference's bilinear resize is the identity
-        return F.relu(self.bn1(self.upconv(x)))
+            x = x + F.interpolate(self._conv_bn(self.lateral[i], self.bn[i], feats[i]), size=size, mode="bilinear", align_corners=False)
+        x = self._conv_bn(self.enc_proj, self.enc_bn, enc_s8, addend=x)  # same size: the reference's bilinear resize is the identity
+        return self._conv_bn(self.upconv, self.bn1, x, act="relu", transposed=True)
 
 
 class DFINETransformer(nn.Module):
@@ -290,7 +306,7 @@ class DFINETransformer(nn.Module):
         part = noise["part_u"] + negative  # negatives jitter by 1..2 box halves, positives by 0..1
         xyxy = (xyxy + (noise["sign01"] * 2.0 - 1.0) * part * reach).clamp(0.0, 1.0)
         box = torch.cat([(xyxy[..., :2] + xyxy[..., 2:]) / 2, xyxy[..., 2:] - xyxy[..., :2]], -1).abs()
-        content = self.denoising_class_embed(cls)
+        content = ops.embedding(cls, self.denoising_class_embed.weight, self.denoising_class_embed.padding_idx)  # HIP backward
         assign = torch.where((slot < G)[None, :] & pad, slot[None, :].expand(B, N), -1)  # GT index of positive slots
         meta = {"dn_num_group": groups, "dn_num_split": [N, spec.num_queries], "dn_assign": assign}
         return content, inverse_sigmoid(box), self._dn_attention_mask(G, groups, dev), meta
@@ -369,9 +385,7 @@ class DFINETransformer(nn.Module):
 
         # ---- mask branch (:999-1022)
         if do_masks:
-            h8, w8 = spatial_shapes[0]
-            mem0 = memory[:, : h8 * w8].transpose(1, 2).reshape(B, hid, h8, w8)
-            mask_feat = self.pixel_decoder(inner_feats, mem0)
+            mask_feat = self.pixel_decoder(inner_feats, proj[0])  # proj[0] IS memory[:, :h8*w8] as a map (no copy)
             mask_of = lambda h: mask_logits(self.mask_head(h), mask_feat)
 
         if not training:

@@ -81,12 +81,16 @@ def linear_forward(x, w, bias=None, relu=False, out=None, name="gemm_fwd"):
     N = w.shape[0]
     if not w.is_contiguous():
         w = w.contiguous()
-    if out is None:
-        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    ldb = pixel_pitch(w)
+    if ldb is None:
+        w = w.contiguous()
+        ldb = K
+    if out is None:  # rows padded to a multiple of 8 columns keep the 16-byte store path (N = 132, 4, ...)
+        out = torch.empty(M, (N + 7) // 8 * 8, dtype=torch.bfloat16, device=x.device)[:, :N]
     ldc = pixel_pitch(out)
     if ldc is None:
         raise _lib.DfineHipError("linear_forward: output must be a pixel-row view")
-    g = _geom(M=M, N=N, K=K, lda=lda, ldb=K, ldc=ldc, gather=0, act=1 if relu else 0)
+    g = _geom(M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, gather=0, act=1 if relu else 0)
     _launch(x, w, out, bias, None, g, name, f"linear M{M} N{N} K{K}")
     return out
 

@@ -62,6 +62,7 @@ class ConvNorm(nn.Module):
         self.norm_name = norm_name
         setattr(self, norm_name, FrozenBatchNorm2d(c_out) if frozen_norm else nn.BatchNorm2d(c_out))
         self.act_name = act
+        self.pad_br = None  # bottom/right padding when it differs from conv.padding (the stem's 2x2 convs)
         if lab and act is not None:
             self.lab = LearnableAffine()
         self._pending_batches = 0
@@ -71,27 +72,35 @@ class ConvNorm(nn.Module):
         """``addend`` (same shape as the output) is added after the norm, before the activation;
         ``act`` overrides the constructor's activation name (used by RepVgg: silu(a + b))."""
         conv = self.conv
+        norm = getattr(self, self.norm_name)
+        frozen = isinstance(norm, FrozenBatchNorm2d)
+        batch_stats = self.training and not frozen
+        ws, have_stats = None, False
         if conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1:
             x = ops.depthwise_conv2d(x, conv.weight, conv.stride[0])  # HIP: MIOpen has no fast path here
         elif (conv.groups == 1 and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1]
               and isinstance(conv.padding[0], int) and conv.dilation == (1, 1)):
-            # library fwd/dgrad, HIP wgrad straight into the fp32 grads
-            x = ops.dense_conv(x, conv.weight, conv.stride[0], conv.padding[0])
+            # HIP implicit-GEMM forward / input gradient, HIP wgrad straight into the fp32 grads; in bf16 training mode
+            # the conv's epilogue leaves the BatchNorm statistics in the norm's workspace (no statistics pass)
+            bf16_mode = x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16)
+            if bf16_mode and batch_stats and isinstance(norm, nn.BatchNorm2d):
+                ws, have_stats = ops.bn_workspace(conv.out_channels, x.device), True
+            x = ops.dense_conv(x, conv.weight, conv.stride[0], conv.padding[0], self.pad_br,
+                               stats=ws[: 32 * conv.out_channels] if have_stats else None)
         else:
+            if self.pad_br is not None:
+                x = F.pad(x, (0, self.pad_br, 0, self.pad_br))
             x = conv(x)
         act_name = act if act is not None else self.act_name
-        norm = getattr(self, self.norm_name)
         lab = getattr(self, "lab", None)
-        frozen = isinstance(norm, FrozenBatchNorm2d)
         fused = (isinstance(norm, nn.BatchNorm2d) or frozen) and ops.batch_norm_act_supported(x, conv.out_channels)
-        if fused:  # HIP: norm + addend + activation + LAB in 2 kernels (2 more in backward); frozen/eval: 1 + 1
-            batch_stats = self.training and not frozen
+        if fused:  # HIP: norm + addend + activation + LAB in 1-2 kernels (2 more in backward); frozen/eval: 1 + 1
             if batch_stats:
                 self._pending_batches += 1
             return ops.batch_norm_act(
                 x, norm.weight, norm.bias, norm.running_mean, norm.running_var, act_name,
                 lab.scale if lab is not None else None, lab.bias if lab is not None else None, addend,
-                training=batch_stats, momentum=getattr(norm, "momentum", 0.1) or 0.1, eps=norm.eps)
+                training=batch_stats, momentum=getattr(norm, "momentum", 0.1) or 0.1, eps=norm.eps, ws=ws, have_stats=have_stats)
         x = norm(x)
         if addend is not None:
             x = x + addend
@@ -145,10 +154,9 @@ class MLP(nn.Module):
         self.layers = nn.ModuleList(Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
     def forward(self, x):
+        last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
-            x = layer(x)
-            if i + 1 < len(self.layers):
-                x = F.relu(x)
+            x = ops.linear(x, layer.weight, layer.bias, relu=i < last)  # bias + ReLU in the GEMM epilogue
         return x
 
 

@@ -355,7 +355,8 @@ class _BatchNormAct(torch.autograd.Function):
     include/dfine_hip.h (dfine_bn_act_*)."""
 
     @staticmethod
-    def forward(ctx, x, addend, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, eps, momentum, training):
+    def forward(ctx, x, addend, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, eps, momentum, training,
+                ws=None, have_stats=False):
         _lib.require_gpu(x, gamma, beta)
         lib = _lib.load()
         B, C, H, W = x.shape
@@ -363,8 +364,10 @@ class _BatchNormAct(torch.autograd.Function):
         al = _nhwc(addend.to(x.dtype)) if addend is not None else None
         n_pix = B * H * W
         y = torch.empty_like(xl)
-        # one zeroed workspace: fp64 sums [8 replicas][2C] (as 32C floats) | save_mean [C] | save_rstd [C]
-        ws = zeros_f32(34 * C, x.device)
+        # one zeroed workspace: fp64 sums [8 replicas][2C] (as 32C floats) | save_mean [C] | save_rstd [C]; with
+        # ``have_stats`` the producing conv's epilogue (dfine_igemm_bf16) has already accumulated the sums into it
+        if ws is None:
+            ws, have_stats = zeros_f32(34 * C, x.device), False
         sums, save_mean, save_rstd = ws[: 32 * C], ws[32 * C : 33 * C], ws[33 * C :]
         g32, b32 = gamma.detach().float(), beta.detach().float()
         ls32 = lab_scale.detach().float() if lab_scale is not None else None
@@ -374,7 +377,7 @@ class _BatchNormAct(torch.autograd.Function):
                 _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean), _lib.ptr(save_rstd), _lib.ptr(ls32),
                 _lib.ptr(lb32), n_pix, C, _ACT_CODES[act], int(training), eps, momentum)
         rc = 0
-        if training:
+        if training and not have_stats:
             with _lib.timed("bn_stats", xl.numel() * es, f"{n_pix}x{C}"):
                 rc = lib.dfine_bn_act_fwd(*args, 1, _lib.stream_ptr())
         with _lib.timed("bn_apply", (xl.numel() + y.numel() + (al.numel() if al is not None else 0)) * es, f"{n_pix}x{C}"):
@@ -424,15 +427,21 @@ class _BatchNormAct(torch.autograd.Function):
             rc = rc or lib.dfine_bn_act_bwd(*args, 2, _lib.stream_ptr())
         _lib.check(rc, "dfine_bn_act_bwd")
         if direct or not wants_param_grads:
-            return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None) + (None,) * 10
+            return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None) + (None,) * 12
         return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None,
                 dgamma.to(g_dtype), dbeta.to(g_dtype), None, None,
                 dlab[0:1].to(lab_dtype) if ls32 is not None else None,
-                dlab[1:2].to(lab_dtype) if ls32 is not None else None, None, None, None, None)
+                dlab[1:2].to(lab_dtype) if ls32 is not None else None, None, None, None, None, None, None)
+
+
+def bn_workspace(channels, device):
+    """Zeroed workspace of one fused BatchNorm call; its first 32*C floats are the fp64 statistics replicas a producing
+    conv may fill (``dense_conv(..., stats=ws[:32 * C])`` then ``batch_norm_act(..., ws=ws, have_stats=True)``)."""
+    return zeros_f32(34 * channels, device)
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, lab_scale=None, lab_bias=None,
-                   addend=None, training=True, momentum=0.1, eps=1e-5):
+                   addend=None, training=True, momentum=0.1, eps=1e-5, ws=None, have_stats=False):
     """Fused ``lab_scale * act(batch_norm(x) + addend) + lab_bias`` on a channels_last map
     (float32 or bfloat16). ``lab_scale`` / ``lab_bias`` are float tensors [1] (both or neither);
     ``act`` is None, "relu" or "silu". In training mode the running statistics are updated in place exactly like
@@ -440,7 +449,7 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, lab_scal
     if x.dtype not in (torch.float32, torch.bfloat16):
         x = x.float()
     return _BatchNormAct.apply(x, addend, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, float(eps),
-                               float(momentum), bool(training))
+                               float(momentum), bool(training), ws, bool(have_stats))
 
 
 def batch_norm_act_supported(x, channels):
@@ -713,106 +722,149 @@ def bf16_of(param):
     return param.to(torch.bfloat16)
 
 
+def transpose_weight(w16):
+    """bf16 weight with memory [K][T][C] (Linear [N, K_in]: T = 1; channels_last conv [CO, CI, KH, KW]) -> dense
+    [C][T][K] (Linear: W^T; conv: [CI, KH, KW, CO]) -- the operand of the input-gradient GEMM."""
+    if w16.dim() == 2:
+        return w16.t().contiguous()
+    return w16.permute(1, 2, 3, 0).contiguous()
+
+
+def bf16_t_of(param):
+    """Transposed bf16 copy of a weight (see ``transpose_weight``): the optimizer-maintained transposed shadow when
+    there is one and it is current, else computed here."""
+    st = getattr(param, "_bf16_shadow_t", None)
+    if st is not None and param._shadow_version == param._version:
+        return st
+    return transpose_weight(bf16_of(param))
+
+
+def _khwc(w16):
+    """[CO, CI, KH, KW] (channels_last memory) -> dense [CO, KH, KW, CI] view (a copy only if it was not channels_last)."""
+    v = w16.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
 class _Linear(torch.autograd.Function):
-    """y = x @ W[rows]^T + b[rows] in bf16 (hipBLASLt), with the weight/bias gradient by the split-M
-    MFMA kernel dfine_linear_wgrad."""
+    """y = relu?(x @ W[rows]^T + b[rows]) in bf16: forward and input gradient by the implicit-GEMM MFMA kernel
+    (dfine_igemm_bf16), weight/bias gradient by the split-M MFMA kernel (dfine_linear_wgrad)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, row_begin, row_end):
-        whole = row_begin == 0 and row_end == weight.shape[0]
+    def forward(ctx, x, weight, bias, row_begin, row_end, relu):
+        from . import gemm
+
         x16 = x.to(torch.bfloat16)
-        if whole or getattr(weight, "_bf16_shadow", None) is not None:
-            w16 = bf16_of(weight)[row_begin:row_end]
-            b16 = bf16_of(bias)[row_begin:row_end] if bias is not None else None
-        else:  # no shadow: cast only the rows used
-            w16 = weight[row_begin:row_end].to(torch.bfloat16)
-            b16 = bias[row_begin:row_end].to(torch.bfloat16) if bias is not None else None
-        y = torch.nn.functional.linear(x16, w16, b16)
-        ctx.save_for_backward(x16, w16)
-        ctx.params = (weight, bias, row_begin, row_end)
-        return y
+        K = weight.shape[1]
+        x2 = x16.reshape(-1, K)
+        w16 = bf16_of(weight)[row_begin:row_end]
+        b32 = bias.detach()[row_begin:row_end].float() if bias is not None else None
+        y = gemm.linear_forward(x2, w16, b32, relu)
+        ctx.save_for_backward(x2, y if relu else None)
+        ctx.params = (weight, bias, row_begin, row_end, relu, x16.shape)
+        return y.reshape(*x16.shape[:-1], row_end - row_begin) if y.is_contiguous() else y.unflatten(0, x16.shape[:-1])
 
     @staticmethod
     def backward(ctx, gy):
-        x16, w16 = ctx.saved_tensors
-        weight, bias, r0, r1 = ctx.params
+        from . import gemm
+
+        x2, y = ctx.saved_tensors
+        weight, bias, r0, r1, relu, x_shape = ctx.params
         lib = _lib.load()
-        N, K = w16.shape
+        N, K = r1 - r0, weight.shape[1]
         gy16 = gy.to(torch.bfloat16).reshape(-1, N)
+        if relu:
+            gy16 = gy16 * (y > 0)
         if not gy16.is_contiguous():
             gy16 = gy16.contiguous()
-        x2 = x16.reshape(-1, K)
-        if not x2.is_contiguous():
-            x2 = x2.contiguous()
         M = x2.shape[0]
-        dx = (gy16 @ w16).view_as(x16) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = bf16_t_of(weight)[:, r0:r1]  # [K, N] rows of pitch N_total: read in place
+            dx = gemm.linear_forward(gy16, wt, None, False, name="gemm_dgrad").view(x_shape)
         direct = (DIRECT_WGRAD_ACCUM and weight.grad is not None and weight.grad.dtype == torch.float32
                   and weight.grad.is_contiguous() and (bias is None or (bias.grad is not None and bias.grad.is_contiguous())))
         if direct:
             dw, db = weight.grad[r0:r1], (bias.grad[r0:r1] if bias is not None else None)
         else:
-            dw = torch.zeros(N, K, dtype=torch.float32, device=x16.device)
-            db = torch.zeros(N, dtype=torch.float32, device=x16.device) if bias is not None else None
+            dw = torch.zeros(N, K, dtype=torch.float32, device=x2.device)
+            db = torch.zeros(N, dtype=torch.float32, device=x2.device) if bias is not None else None
         with _lib.timed("wgrad", (M * N + M * K) * 2 + N * K * 4, f"linear M{M} N{N} K{K}"):
-            rc = lib.dfine_linear_wgrad(_lib.ptr(gy16), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), M, N, K, K, _lib.stream_ptr())
+            rc = lib.dfine_linear_wgrad(_lib.ptr(gy16), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), M, N, K, K, N, K, _lib.stream_ptr())
         _lib.check(rc, "dfine_linear_wgrad")
         if direct:
-            return dx, None, None, None, None
+            return dx, None, None, None, None, None
         full_w = dw if (r0 == 0 and r1 == weight.shape[0]) else torch.zeros_like(weight, dtype=torch.float32).index_put_((torch.arange(r0, r1, device=dw.device),), dw)
         full_b = None
         if bias is not None:
             full_b = db if (r0 == 0 and r1 == bias.shape[0]) else torch.zeros_like(bias, dtype=torch.float32).index_put_((torch.arange(r0, r1, device=db.device),), db)
-        return dx, full_w.to(weight.dtype), (full_b.to(bias.dtype) if full_b is not None else None), None, None
+        return dx, full_w.to(weight.dtype), (full_b.to(bias.dtype) if full_b is not None else None), None, None, None
 
 
-def linear(x, weight, bias=None, row_begin=0, row_end=None):
-    """``F.linear(x, weight[row_begin:row_end], bias[row_begin:row_end])``. On the GPU in bf16 mode
-    (autocast, or bf16 input) the forward and the input gradient are library GEMMs and the weight/bias
-    gradient is the split-M HIP kernel; otherwise (fp32 parity runs, odd N or K) it is plain ``F.linear``."""
+def linear(x, weight, bias=None, row_begin=0, row_end=None, relu=False):
+    """``relu?(F.linear(x, weight[row_begin:row_end], bias[row_begin:row_end]))``. On the GPU in bf16 mode (autocast, or
+    bf16 input) forward, input gradient and weight/bias gradient are all HIP MFMA kernels; otherwise (fp32 parity
+    runs, inference without grad on odd shapes) it is plain ``F.linear``."""
     row_end = weight.shape[0] if row_end is None else row_end
     n, k = row_end - row_begin, weight.shape[1]
     bf16_mode = x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16)
-    if not bf16_mode or n % 2 or k % 2 or not (weight.requires_grad and torch.is_grad_enabled()):
+    if not bf16_mode or n % 2 or k % 2:
         w = weight if (row_begin == 0 and row_end == weight.shape[0]) else weight[row_begin:row_end]
         b = bias if (bias is None or (row_begin == 0 and row_end == weight.shape[0])) else bias[row_begin:row_end]
-        return torch.nn.functional.linear(x, w, b)
-    return _Linear.apply(x, weight, bias, row_begin, row_end)
+        y = torch.nn.functional.linear(x, w, b)
+        return torch.relu(y) if relu else y
+    if not (torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)):
+        from . import gemm
+
+        x16 = x.to(torch.bfloat16)
+        b32 = bias.detach()[row_begin:row_end].float() if bias is not None else None
+        y = gemm.linear_forward(x16.reshape(-1, k), bf16_of(weight)[row_begin:row_end], b32, relu)
+        return y.reshape(*x16.shape[:-1], n) if y.is_contiguous() else y.unflatten(0, x16.shape[:-1])
+    return _Linear.apply(x, weight, bias, row_begin, row_end, bool(relu))
 
 
 class _DenseConv(torch.autograd.Function):
-    """Dense (groups = 1, no bias) convolution on a channels_last map: forward and input gradient by the
-    library (MIOpen), weight gradient by the split-M MFMA kernel with gathered rows (for a 1x1 conv it
-    is exactly a Linear's: dW[k][c] = sum over pixels of dY[pix][k] * X[pix][c]) accumulated straight
-    into the fp32 .grad."""
+    """Dense (groups = 1, no bias) convolution on a channels_last map, all three passes on MFMA kernels of this
+    library: forward and input gradient by the implicit-GEMM kernel (dfine_igemm_bf16; the forward can leave the
+    following BatchNorm's statistics in ``stats`` and write into a channel slice ``out``), weight gradient by the
+    split-M kernel with gathered rows, accumulated straight into the fp32 .grad."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding):
-        w16 = bf16_of(weight)
+    def forward(ctx, x, weight, stride, padding, pad_br, stats, out):
+        from . import gemm
+
         x16 = x.to(torch.bfloat16)
-        if not x16.is_contiguous(memory_format=torch.channels_last):
-            # a channel slice (chunk / cat gradient views): the library conv would copy it internally and the
-            # backward's wgrad again -- make the one dense copy here and keep it
-            x16 = x16.contiguous(memory_format=torch.channels_last)
-        y = torch.nn.functional.conv2d(x16, w16, None, stride, padding)
-        ctx.save_for_backward(x16, w16)
-        ctx.weight, ctx.geom = weight, (stride, padding)
-        return y
+        xl = gemm.nhwc(x16)
+        if gemm.pixel_pitch(xl) is None:
+            xl = xl.contiguous()
+        wk = _khwc(bf16_of(weight))
+        stats64 = stats if stats is not None else None
+        yl = gemm.conv_forward(xl, wk, stride, padding, pad_br, out=gemm.nhwc(out) if out is not None else None, stats=stats64)
+        ctx.save_for_backward(xl)
+        ctx.weight, ctx.geom = weight, (stride, padding, pad_br)
+        if out is not None:
+            ctx.mark_dirty(out)
+            return out
+        return yl.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, gy):
-        x16, w16 = ctx.saved_tensors
+        from . import gemm
+
+        (xl,) = ctx.saved_tensors
         weight = ctx.weight
-        stride, padding = ctx.geom
+        stride, padding, pad_br = ctx.geom
         lib = _lib.load()
-        K_out, C_in, KH, KW = w16.shape
-        gy16 = gy.to(torch.bfloat16)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(gy16, x16, w16, None, (stride, stride), (padding, padding), (1, 1),
-                                                     False, (0, 0), 1, (True, False, False))[0]
-        gyl, xl = _nhwc(gy16), _nhwc(x16)  # [B,OH,OW,K], [B,H,W,C]: row-major [pixels, channels]
+        K_out, C_in, KH, KW = weight.shape
+        gyl = gemm.nhwc(gy.to(torch.bfloat16))
+        if gemm.pixel_pitch(gyl) is None:
+            gyl = gyl.contiguous()
         B, H, W, _ = xl.shape
         OH, OW = gyl.shape[1], gyl.shape[2]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm.conv_input_grad(gyl, bf16_t_of(weight), (H, W), stride, padding).permute(0, 3, 1, 2)
+        gyc, xc = gyl, xl  # pixel rows of pitch ldy / ldx (channel slices are read in place)
+        ldy, ldx = gemm.pixel_pitch(gyc), gemm.pixel_pitch(xc)
         taps = KH * KW
         # the fp32 gradient must be laid out [K_out][KH][KW][C_in] (a channels_last weight's memory order)
         direct = (DIRECT_WGRAD_ACCUM and weight.grad is not None and weight.grad.dtype == torch.float32
@@ -822,12 +874,12 @@ class _DenseConv(torch.autograd.Function):
         else:
             dw = torch.zeros(K_out, C_in, KH, KW, dtype=torch.float32, device=xl.device).contiguous(memory_format=torch.channels_last)
         M = B * OH * OW
-        with _lib.timed("wgrad", (M * K_out + xl.numel()) * 2 + K_out * C_in * taps * 4,
+        with _lib.timed("wgrad", (M * K_out + xc.numel()) * 2 + K_out * C_in * taps * 4,
                         f"conv {B}x{H}x{W} {C_in}->{K_out} k{KH}s{stride}"):
-            rc = lib.dfine_conv_wgrad(_lib.ptr(gyl), _lib.ptr(xl), _lib.ptr(dw), B, H, W, C_in, OH, OW, K_out, KH, KW,
-                                      stride, padding, _lib.stream_ptr())
+            rc = lib.dfine_conv_wgrad(_lib.ptr(gyc), _lib.ptr(xc), _lib.ptr(dw), B, H, W, C_in, OH, OW, K_out, KH, KW,
+                                      stride, padding, ldy, ldx, _lib.stream_ptr())
         _lib.check(rc, "dfine_conv_wgrad")
-        return dx, (None if direct else dw.to(weight.dtype)), None, None
+        return dx, (None if direct else dw.to(weight.dtype)), None, None, None, None, None
 
 
 def _is_khwc(t):
@@ -837,15 +889,122 @@ def _is_khwc(t):
     return all(t.shape[d] == 1 or t.stride(d) == want[d] for d in range(4))
 
 
-def dense_conv(x, weight, stride=1, padding=0):
-    """``F.conv2d(x, weight, None, stride, padding)`` for a groups=1 conv without bias on a
-    channels_last map. In bf16 training mode the weight gradient comes from the HIP split-M kernel (no
-    MIOpen fp32 workspace, cast and accumulate launches); otherwise this is plain ``F.conv2d``."""
-    k_out, c_in = weight.shape[0], weight.shape[1]
+def dense_conv(x, weight, stride=1, padding=0, pad_br=None, stats=None, out=None):
+    """``F.conv2d(x, weight, None, stride, padding)`` for a groups=1 conv without bias on a channels_last map
+    (``pad_br``: bottom/right padding when it differs from ``padding``, which then pads top/left only). In bf16 mode on
+    the GPU all three passes are HIP MFMA kernels; ``stats`` (fp32 view of the fp64 replicas, ``bn_workspace``) receives
+    the output's per-channel sums for the BatchNorm that follows; ``out`` (an NCHW-shaped channels_last view, e.g. a
+    channel slice of a concat buffer) receives the result in place. Otherwise this is plain ``F.conv2d``."""
     bf16_mode = x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16)
-    if not bf16_mode or k_out % 2 or c_in % 8 or not (weight.requires_grad and torch.is_grad_enabled()):
+    if not bf16_mode:
+        if stats is not None or out is not None:
+            raise _lib.DfineHipError("dense_conv: stats/out need the bf16 GPU path")
+        if pad_br is not None and pad_br != padding:
+            x = torch.nn.functional.pad(x, (padding, pad_br, padding, pad_br))
+            padding = 0
         return torch.nn.functional.conv2d(x, weight, None, stride, padding)
-    return _DenseConv.apply(x, weight, int(stride), int(padding))
+    if not (torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)):
+        from . import gemm
+
+        xl = gemm.nhwc(x.to(torch.bfloat16))
+        yl = gemm.conv_forward(xl, _khwc(bf16_of(weight)), stride, padding, pad_br, out=gemm.nhwc(out) if out is not None else None,
+                               stats=stats)
+        return out if out is not None else yl.permute(0, 3, 1, 2)
+    return _DenseConv.apply(x, weight, int(stride), int(padding), pad_br, stats, out)
+
+
+class _ConvTranspose2x2(torch.autograd.Function):
+    """nn.ConvTranspose2d(kernel 2, stride 2, no bias) on a channels_last map: forward = four 1-tap implicit-GEMM
+    launches writing interleaved output pixels, input gradient = one 4-tap stride-2 gather, weight gradient = the
+    split-M conv wgrad kernel with the roles of input and output gradient swapped."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stats):
+        from . import gemm
+
+        xl = gemm.nhwc(x.to(torch.bfloat16))
+        if gemm.pixel_pitch(xl) is None:
+            xl = xl.contiguous()
+        yl = gemm.conv_transpose2x2_forward(xl, bf16_t_of(weight), stats=stats)  # transposed copy: [CO, 2, 2, CI]
+        ctx.save_for_backward(xl)
+        ctx.weight = weight
+        return yl.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import gemm
+
+        (xl,) = ctx.saved_tensors
+        weight = ctx.weight
+        lib = _lib.load()
+        CI, CO = weight.shape[0], weight.shape[1]
+        gyl = gemm.nhwc(gy.to(torch.bfloat16))
+        if gemm.pixel_pitch(gyl) is None:
+            gyl = gyl.contiguous()
+        B, H, W, _ = xl.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm.conv_transpose2x2_input_grad(gyl, _khwc(bf16_of(weight))).permute(0, 3, 1, 2)
+        direct = (DIRECT_WGRAD_ACCUM and weight.grad is not None and weight.grad.dtype == torch.float32 and _is_khwc(weight.grad))
+        dw = weight.grad if direct else torch.zeros(CI, CO, 2, 2, dtype=torch.float32, device=xl.device).contiguous(memory_format=torch.channels_last)
+        M = B * H * W
+        with _lib.timed("wgrad", (M * CI + gyl.numel()) * 2 + CI * CO * 16, f"convT {B}x{H}x{W} {CI}->{CO}"):
+            rc = lib.dfine_conv_wgrad(_lib.ptr(xl), _lib.ptr(gyl), _lib.ptr(dw), B, 2 * H, 2 * W, CO, H, W, CI, 2, 2, 2, 0,
+                                      gemm.pixel_pitch(xl), gemm.pixel_pitch(gyl), _lib.stream_ptr())
+        _lib.check(rc, "dfine_conv_wgrad")
+        return dx, (None if direct else dw.to(weight.dtype)), None
+
+
+def conv_transpose2x2(x, weight, stats=None):
+    """``F.conv_transpose2d(x, weight, None, stride=2)`` for a [CI, CO, 2, 2] weight on a channels_last map; bf16 GPU path
+    on the HIP kernels (``stats``: see ``dense_conv``), otherwise the stock op."""
+    bf16_mode = x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16)
+    if not bf16_mode or tuple(weight.shape[2:]) != (2, 2):
+        if stats is not None:
+            raise _lib.DfineHipError("conv_transpose2x2: stats need the bf16 GPU path")
+        return torch.nn.functional.conv_transpose2d(x, weight, None, 2)
+    if not (torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)):
+        from . import gemm
+
+        return gemm.conv_transpose2x2_forward(gemm.nhwc(x.to(torch.bfloat16)), bf16_t_of(weight), stats=stats).permute(0, 3, 1, 2)
+    return _ConvTranspose2x2.apply(x, weight, stats)
+
+
+class _Embedding(torch.autograd.Function):
+    """nn.Embedding lookup whose weight gradient is ONE HIP launch of float atomics into the fp32 gradient
+    (dfine_embedding_wgrad) instead of ATen's sort / unique-by-key / segment pipeline."""
+
+    @staticmethod
+    def forward(ctx, idx, weight, padding_idx):
+        ctx.save_for_backward(idx)
+        ctx.weight, ctx.padding_idx = weight, padding_idx
+        return weight.detach().index_select(0, idx.reshape(-1)).view(*idx.shape, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        weight, padding_idx = ctx.weight, ctx.padding_idx
+        lib = _lib.load()
+        rows, D = weight.shape
+        g = g.contiguous()
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        direct = DIRECT_WGRAD_ACCUM and weight.grad is not None and weight.grad.dtype == torch.float32 and weight.grad.is_contiguous()
+        dw = weight.grad if direct else torch.zeros(rows, D, dtype=torch.float32, device=g.device)
+        flat = idx.reshape(-1).contiguous()
+        with _lib.timed("embedding_wgrad", flat.numel() * D * (g.element_size() + 4)):
+            rc = lib.dfine_embedding_wgrad(_lib.ptr(flat), _lib.ptr(g), _lib.dtype_code(g), _lib.ptr(dw), flat.numel(), D, rows,
+                                           -1 if padding_idx is None else int(padding_idx), _lib.stream_ptr())
+        _lib.check(rc, "dfine_embedding_wgrad")
+        return None, (None if direct else dw.to(weight.dtype)), None
+
+
+def embedding(idx, weight, padding_idx=None):
+    """``F.embedding(idx, weight, padding_idx)`` (idx int64, any shape). On the GPU the backward is the HIP atomic
+    kernel; on the CPU this is the stock op."""
+    if not (idx.is_cuda and weight.is_cuda) or not (weight.requires_grad and torch.is_grad_enabled()):
+        return torch.nn.functional.embedding(idx, weight, padding_idx)
+    return _Embedding.apply(idx.to(torch.int64), weight, padding_idx)
 
 
 def pointwise_conv(x, weight):

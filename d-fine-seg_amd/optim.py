@@ -53,9 +53,13 @@ class FlatState:
                     continue
                 if p.dtype != torch.float32:
                     raise TypeError(f"{name}: fused optimizer expects fp32 master weights, got {p.dtype}")
+                # every tensor starts on a multiple of 8 elements: its bf16 shadow (and transposed shadow) is then 16-byte
+                # aligned, which the GEMM kernels' vector loads need (scalars such as the LAB scale/bias would otherwise
+                # misalign everything behind them); the padding is zero in every flat buffer and stays zero
+                offset = (offset + 7) // 8 * 8
                 self.entries.append((name, p, offset, p.numel(), gi))
                 offset += p.numel()
-            offset = (offset + 3) // 4 * 4  # keep every group 16-byte aligned
+            offset = (offset + 7) // 8 * 8  # groups start aligned too
         self.numel = offset
         device = self.entries[0][1].device
         self.device = device
@@ -77,15 +81,60 @@ class FlatState:
         weight in ~300 small launches per step. A parameter changed behind the optimizer's back (its
         ``_version`` moved: ``load_state_dict``, ``copy_``) is cast again until ``refresh_bf16_shadow``."""
         self.shadow = torch.empty(self.numel, dtype=torch.bfloat16, device=self.device)
+        # transposed shadow: every GEMM weight (Linear [N, K]; dense conv / transposed conv in channels_last memory
+        # [d0][kh][kw][d1]) also as [K][N] / [d1][kh][kw][d0] -- the operand of the input-gradient GEMMs -- rewritten by
+        # ONE transpose launch after each optimizer step (dfine_transpose_weights)
+        self.shadow_t = torch.empty(self.numel, dtype=torch.bfloat16, device=self.device)
+        rows, blocks = [], []
+        self._transposed = []
+        for name, p, off, n, _ in self.entries:
+            ktc = self.weight_ktc(p)
+            if ktc is None:
+                continue
+            K, T, C = ktc
+            tiles = T * ((K + 31) // 32) * ((C + 31) // 32)
+            blocks.extend((len(rows), t) for t in range(tiles))
+            rows.append((off, off, K, T, C))
+            self._transposed.append((p, off, n, (C, K) if p.dim() == 2 else (C, p.shape[2], p.shape[3], K)))
+        self._t_table = torch.tensor(rows, dtype=torch.int64, device=self.device) if rows else None
+        self._t_blocks = torch.tensor(blocks, dtype=torch.int32, device=self.device) if rows else None
         self.refresh_bf16_shadow()
+
+    @staticmethod
+    def weight_ktc(p):
+        """(K, T, C) when ``p``'s memory is a dense [K][T][C] GEMM weight: Linear [N, K_in] -> (N, 1, K_in); a
+        channels_last conv weight [d0, d1, kh, kw] with d1 > 1 -> (d0, kh*kw, d1). None otherwise."""
+        if p.dim() == 2 and p.is_contiguous():
+            return p.shape[0], 1, p.shape[1]
+        if p.dim() == 4 and p.shape[1] > 1:
+            d0, d1, kh, kw = p.shape
+            want = (kh * kw * d1, 1, kw * d1, d1)
+            if all(p.shape[d] == 1 or p.stride(d) == want[d] for d in range(4)):
+                return d0, kh * kw, d1
+        return None
+
+    def launch_transpose(self):
+        """Rewrite the transposed shadow from the bf16 shadow (one launch, graph-capturable)."""
+        if self.shadow is None or self._t_table is None:
+            return
+        lib = _lib.load()
+        with _lib.timed("transpose_weights", self.numel * 4):
+            rc = lib.dfine_transpose_weights(_lib.ptr(self.shadow), _lib.ptr(self.shadow_t), _lib.ptr(self._t_table),
+                                             _lib.ptr(self._t_blocks), self._t_blocks.shape[0], _lib.stream_ptr())
+        _lib.check(rc, "dfine_transpose_weights")
 
     def refresh_bf16_shadow(self):
         if self.shadow is None:
             return
         self.shadow.copy_(self.params)
+        if self.device.type == "cuda":
+            self.launch_transpose()
         for name, p, off, n, _ in self.entries:
             p._bf16_shadow = self.view_like(self.shadow, p, off)
             p._shadow_version = p._version
+        if self.device.type == "cuda":
+            for p, off, n, shape in self._transposed:
+                p._bf16_shadow_t = self.shadow_t[off : off + n].view(shape)
 
     def bf16_shadow_is_current(self):
         return self.shadow is None or all(p._shadow_version == p._version for _, p, _, _, _ in self.entries)
@@ -163,6 +212,7 @@ class FusedAdamWEMA:
                                           _lib.ptr(self.ema_flat), _lib.ptr(f.shadow), _lib.ptr(self.hyper), _lib.ptr(self.sumsq),
                                           self._group_begin, len(f.group_begin), f.numel, st)
         _lib.check(rc, "dfine_adamw_ema_step")
+        f.launch_transpose()  # the transposed bf16 shadow follows the bf16 shadow the kernel above rewrote
 
     def step(self):
         self._upload_scalars()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 1
+#define DFINE_ABI_VERSION 2
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -214,25 +214,30 @@ int dfine_criterion_head(const void* logits, int logits_dtype, const float* boxe
  * projection and MLP of the decoder and the AIFI layer: src/d_fine/arch/dfine_decoder.py:33-46,
  * 181-271; hybrid_encoder.py:243-290), split over the token axis, bf16 MFMA, fp32 accumulation:
  *     dW[n][k] += sum_m dY[m][n] * X[m][k]          db[n] += sum_m dY[m][n]   (db may be NULL)
- *   dY [M, N] bf16, X [M, K] bf16 (row-major); dW f32 rows of length K with leading dimension ldw
- *   (>= K), db f32 [N]. Both are ACCUMULATED with float atomics: point them at the fp32 gradient
- *   buffer itself (or at zeroed scratch). Needs N and K even (4-byte aligned rows).
+ *   dY [M, N] bf16 rows of pitch ldy (>= N), X [M, K] bf16 rows of pitch ldx (>= K); dW f32 rows of length K
+ *   with leading dimension ldw (>= K), db f32 [N]. Both are ACCUMULATED with float atomics: point them at the
+ *   fp32 gradient buffer itself (or at zeroed scratch). Any N, K, pitch and alignment (16-byte vector loads
+ *   when everything is a multiple of 8 elements, narrower loads otherwise).
  * ------------------------------------------------------------------------------------- */
 int dfine_linear_wgrad(const void* dY, const void* X, float* dW, float* db, int M, int N, int K, int ldw,
-                       void* stream);
+                       int ldy, int ldx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Weight gradient of a dense (groups = 1, no bias) 2-d convolution on channels_last maps (autograd
  * of the nn.Conv2d inside ConvBNAct, src/d_fine/arch/hgnetv2.py:35-80, and ConvNormLayer,
  * hybrid_encoder.py:21-93), same split-M MFMA kernel with gathered X rows:
  *     dW[n][ky][kx][c] += sum_{b,oy,ox} dY[b][oy][ox][n] * X[b][oy*stride-pad+ky][ox*stride-pad+kx][c]
- *   dY [B, OH, OW, CO] bf16, X [B, H, W, CI] bf16 (NHWC memory); dW f32 [CO][KH][KW][CI] -- the memory
- *   order of a channels_last weight -- ACCUMULATED with float atomics (point it at the fp32 gradient
- *   or at zeroed scratch). OH/OW must equal (H + 2*pad - KH) / stride + 1 (resp. W, KW).
- *   Needs CI % 8 == 0 and CO even.
+ *   dY [B, OH, OW, CO] bf16 pixels of pitch ldy (>= CO), X [B, H, W, CI] bf16 pixels of pitch ldx (>= CI) (NHWC
+ *   memory, possibly channel slices of wider maps); dW f32 [CO][KH][KW][CI] -- the memory order of a
+ *   channels_last weight -- ACCUMULATED with float atomics (point it at the fp32 gradient or at zeroed scratch).
+ *   `pad` is the top/left padding; the bottom/right padding is implied by OH/OW (taps beyond the map read zeros;
+ *   the stem's F.pad(x, (0,1,0,1)) + 2x2 conv is pad = 0 with OH = H), the last output's first tap must start
+ *   inside the map. Any channel counts (CI % 8 != 0, e.g. the 3-channel image: element-wise gather).
+ *   With a swapped reading it is also the weight gradient of ConvTranspose2d(k = stride, no bias): pass the module's
+ *   INPUT as dY and its output gradient as X (dW [CI][KH][KW][CO] = its channels_last weight's memory order).
  * ------------------------------------------------------------------------------------- */
 int dfine_conv_wgrad(const void* dY, const void* X, float* dW, int B, int H, int W, int CI, int OH, int OW,
-                     int CO, int KH, int KW, int stride, int pad, void* stream);
+                     int CO, int KH, int KW, int stride, int pad, int ldy, int ldx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * FDR head of one decoder layer (reference src/d_fine/arch/dfine_decoder.py:276-296 Integral,

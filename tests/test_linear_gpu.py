@@ -22,7 +22,7 @@ def test_linear_wgrad_matches_fp32_reference(hip_lib, M, N, K):
     x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
     dw = torch.zeros(N, K, device="cuda")
     db = torch.zeros(N, device="cuda")
-    rc = hip_lib.dfine_linear_wgrad(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db), M, N, K, K, _lib.stream_ptr())
+    rc = hip_lib.dfine_linear_wgrad(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db), M, N, K, K, N, K, _lib.stream_ptr())
     assert rc == 0
     ref_w = dy.float().t() @ x.float()
     ref_b = dy.float().sum(0)
@@ -31,7 +31,7 @@ def test_linear_wgrad_matches_fp32_reference(hip_lib, M, N, K):
     torch.testing.assert_close(dw, ref_w, rtol=1e-4, atol=tol * 4)
     torch.testing.assert_close(db, ref_b, rtol=1e-4, atol=tol * 4)
     # accumulation semantics: a second call adds on top
-    hip_lib.dfine_linear_wgrad(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), None, M, N, K, K, _lib.stream_ptr())
+    hip_lib.dfine_linear_wgrad(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), None, M, N, K, K, N, K, _lib.stream_ptr())
     torch.testing.assert_close(dw, 2 * ref_w, rtol=1e-4, atol=tol * 8)
 
 
@@ -40,7 +40,11 @@ def test_unsupported_shape_is_rejected(hip_lib):
 
     t = torch.zeros(16, 13, device="cuda", dtype=torch.bfloat16)
     out = torch.zeros(13, 13, device="cuda")
-    assert hip_lib.dfine_linear_wgrad(_lib.ptr(t), _lib.ptr(t), _lib.ptr(out), None, 16, 13, 13, 13, None) == -2  # odd: rows not 4-byte aligned
+    assert hip_lib.dfine_linear_wgrad(_lib.ptr(t), _lib.ptr(t), _lib.ptr(out), None, 16, 13, 13, 12, 13, 13, None) == -1  # ldw < K
+    # odd N / K (rows only 2-byte aligned) are supported: element-wise loads
+    x = torch.randn(16, 13, device="cuda").bfloat16()
+    assert hip_lib.dfine_linear_wgrad(_lib.ptr(x), _lib.ptr(x), _lib.ptr(out), None, 16, 13, 13, 13, 13, 13, None) == 0
+    torch.testing.assert_close(out, x.float().t() @ x.float(), rtol=1e-4, atol=1e-4)
 
 
 def test_ops_linear_matches_torch_autograd(hip_lib):
@@ -106,6 +110,9 @@ def test_pointwise_conv_matches_torch(hip_lib):
     (1, 9, 9, 8, 8, 5, 1, 2),        # 5x5, tiny
     (2, 16, 16, 24, 40, 3, 1, 1),    # channel counts that are multiples of 8 only
     (2, 33, 33, 24, 12, 2, 1, 0),    # stem2a: 12 output channels
+    (2, 33, 33, 12, 24, 2, 1, 0),    # stem2b: 12 input channels (chunks straddle taps)
+    (2, 32, 32, 3, 24, 3, 2, 1),     # stem1: the 3-channel image
+    (2, 10, 10, 21, 21, 3, 1, 1),    # D-FINE-n's 21-channel CSP branch
 ])
 def test_conv_wgrad_matches_fp32_reference(hip_lib, B, H, W, CI, CO, k, stride, pad):
     import torch.nn.functional as F
@@ -120,7 +127,7 @@ def test_conv_wgrad_matches_fp32_reference(hip_lib, B, H, W, CI, CO, k, stride, 
     F.conv2d(x.float(), w, None, stride, pad).backward(gy.float())
     dw = torch.zeros(CO, k, k, CI, device="cuda")  # [K][KH][KW][C]
     rc = hip_lib.dfine_conv_wgrad(_lib.ptr(gy.permute(0, 2, 3, 1)), _lib.ptr(x.permute(0, 2, 3, 1)), _lib.ptr(dw),
-                                  B, H, W, CI, OH, OW, CO, k, k, stride, pad, _lib.stream_ptr())
+                                  B, H, W, CI, OH, OW, CO, k, k, stride, pad, CO, CI, _lib.stream_ptr())
     assert rc == 0
     M = B * OH * OW
     tol = (3e-8 * M + 2e-4) * 4
@@ -132,10 +139,9 @@ def test_conv_wgrad_rejects_inconsistent_geometry(hip_lib):
 
     t = torch.zeros(1, 8, 8, 8, device="cuda", dtype=torch.bfloat16)
     out = torch.zeros(8, 3, 3, 8, device="cuda")
-    # 8x8 input, 3x3 pad 1 stride 1 gives 8x8, not 7x7
-    assert hip_lib.dfine_conv_wgrad(_lib.ptr(t), _lib.ptr(t), _lib.ptr(out), 1, 8, 8, 8, 7, 7, 8, 3, 3, 1, 1, None) == -1
-    t12 = torch.zeros(1, 8, 8, 12, device="cuda", dtype=torch.bfloat16)
-    assert hip_lib.dfine_conv_wgrad(_lib.ptr(t), _lib.ptr(t12), _lib.ptr(out), 1, 8, 8, 12, 8, 8, 8, 3, 3, 1, 1, None) == -2
+    # 8x8 input, 3x3 pad 1 stride 1: an 11x11 output would start its last taps beyond the map
+    assert hip_lib.dfine_conv_wgrad(_lib.ptr(t), _lib.ptr(t), _lib.ptr(out), 1, 8, 8, 8, 11, 11, 8, 3, 3, 1, 1, 8, 8, None) == -1
+    assert hip_lib.dfine_conv_wgrad(_lib.ptr(t), _lib.ptr(t), _lib.ptr(out), 1, 8, 8, 8, 8, 8, 8, 3, 3, 1, 1, 4, 8, None) == -1  # pitch < channels
 
 
 @pytest.mark.parametrize("k,stride,pad", [(3, 1, 1), (3, 2, 1), (2, 1, 0)])

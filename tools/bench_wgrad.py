@@ -29,7 +29,7 @@ for B, ci, co, H in shapes:
     M = B*H*H
     xl, gl = x.permute(0,2,3,1), gy.permute(0,2,3,1)
     def hip():
-        lib.dfine_linear_wgrad(_lib.ptr(gl), _lib.ptr(xl), _lib.ptr(dw), None, M, co, ci, ci, _lib.stream_ptr())
+        lib.dfine_linear_wgrad(_lib.ptr(gl), _lib.ptr(xl), _lib.ptr(dw), None, M, co, ci, ci, co, ci, _lib.stream_ptr())
     tm, th = timeit(mi), timeit(hip)
     tf = 2.0 * M * ci * co / th / 1e6
     print(f"  {ci:5d}->{co:5d} @{H:3d} M={M:7d}: {tm:8.1f} | {th:8.1f}   {'HIP' if th < tm else 'miopen'}  ({tf:.0f} TFLOP/s)")
@@ -45,7 +45,7 @@ for B, ci, co, H, st in [(32,32,32,160,1),(32,32,64,160,1),(32,64,64,160,1),(32,
         return torch.ops.aten.convolution_backward(gy, x, w, None, (st,st), (1,1), (1,1), False, (0,0), 1, (False, True, False))[1].float()
     xl, gl = x.permute(0,2,3,1), gy.permute(0,2,3,1)
     def hip():
-        lib.dfine_conv_wgrad(_lib.ptr(gl), _lib.ptr(xl), _lib.ptr(dw), B, H, H, ci, OH, OH, co, 3, 3, st, 1, _lib.stream_ptr())
+        lib.dfine_conv_wgrad(_lib.ptr(gl), _lib.ptr(xl), _lib.ptr(dw), B, H, H, ci, OH, OH, co, 3, 3, st, 1, co, ci, _lib.stream_ptr())
     tm, th = timeit(mi), timeit(hip)
     tf = 2.0 * B * OH * OH * 9 * ci * co / th / 1e6
     print(f"  {ci:5d}->{co:5d} @{H:3d} s{st}: {tm:8.1f} | {th:8.1f}   {'HIP' if th < tm else 'miopen'}  ({tf:.0f} TFLOP/s)")
@@ -54,6 +54,6 @@ for M, N, K in [(15744,1024,256),(15744,256,1024),(15744,256,256),(15744,512,512
     dy = torch.randn(M, N, device="cuda", dtype=torch.bfloat16); x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     dw = torch.zeros(N, K, device="cuda")
     def bl(): return (dy.t() @ x).float()
-    def hip(): lib.dfine_linear_wgrad(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), None, M, N, K, K, _lib.stream_ptr())
+    def hip(): lib.dfine_linear_wgrad(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(dw), None, M, N, K, K, N, K, _lib.stream_ptr())
     tb, th = timeit(bl), timeit(hip)
     print(f"  M={M:7d} N={N:5d} K={K:5d}: {tb:8.1f} | {th:8.1f}   {'HIP' if th < tb else 'blaslt'}")
