@@ -79,9 +79,7 @@ def linear_forward(x, w, bias=None, relu=False, out=None, name="gemm_fwd"):
     x, lda = as_pixel_rows(x)
     M, K = x.shape
     N = w.shape[0]
-    if not w.is_contiguous():
-        w = w.contiguous()
-    ldb = pixel_pitch(w)
+    ldb = pixel_pitch(w)  # a row slice of a wider matrix (the transposed shadow's columns) is read in place
     if ldb is None:
         w = w.contiguous()
         ldb = K
