@@ -43,7 +43,7 @@ def parse():
                     help="N>1: eager step + bucketed all-reduce overlapped with backward (default: captured graphs + one flat all-reduce)")
     ap.add_argument("--force-ddp", action="store_true",
                     help="diagnostic: take the N>1 code path (process group, reducer, split graphs) even with one rank")
-    ap.add_argument("--graph-masks", action="store_true", help="segment task: capture the step with the mask branch too (default: eager)")
+    ap.add_argument("--no-graph-masks", action="store_true", help="segment task: run mask batches eagerly (default: captured like detect)")
     ap.add_argument("--shapes", action="store_true", help="diagnostic: key the per-kernel timings by operand shape")
     return ap.parse_args()
 
@@ -153,7 +153,7 @@ def main():
     torch.backends.cudnn.benchmark = not args.no_miopen_find
     torch.manual_seed(42 + rank)  # per-rank seed like train.py:131
     trainer = TrainStep(args.model, 80, seg, (args.img, args.img), device, total_steps=max(1000, args.steps + args.warmup + 1),
-                        grad_reducer=reducer, use_graph=not args.no_graph, graph_masks=args.graph_masks)
+                        grad_reducer=reducer, use_graph=not args.no_graph, graph_masks=not args.no_graph_masks)
     images, targets = synthetic_batch(args.batch, args.img, args.img, 80, args.gts, with_masks=seg, seed=42 + rank, device=device)
     images = images.contiguous(memory_format=torch.channels_last)
 
@@ -166,8 +166,10 @@ def main():
         trainer.step(images, targets)  # eager steps (MIOpen tuning, caches), then the hipGraph capture
     sync()
     t0 = time.perf_counter()
+    replayed = 0
     for _ in range(args.steps):
         loss = trainer.step(images, targets)
+        replayed += int(trainer.last_step_replayed)
     sync()
     elapsed = time.perf_counter() - t0
     # Per-kernel durations: HIP events around every hand-written launch, on the launch stream. The timed
@@ -225,7 +227,8 @@ def main():
                                    f"{args.gts} GT/img ({Lq} decoder queries), COCO-80 synthetic",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "loss": round(loss_value, 4),
-            "hip_graph": bool(graph_was_on),
+            "hip_graph": replayed == args.steps,  # every timed step replayed a captured graph
+            "graph_replays": replayed,
             "peak_device_memory_GB": round(torch.cuda.max_memory_allocated(device) / 2**30, 2),
             "roofline": roofline,
         }

@@ -97,6 +97,9 @@ class BucketedGradReducer:
             with torch.no_grad():
                 for t in tensors:
                     dist.broadcast(t, src=0, group=process_group)
+            # the broadcast wrote the flat base in place, which does not move the parameter views' versions: the bf16
+            # (and transposed) shadows built before it would silently keep this rank's pre-broadcast weights
+            self.flat.refresh_bf16_shadow()
         self.buckets = [_Bucket(b, self.flat.grads) for b in assign_buckets(self.flat.entries, num_buckets)]
         self._owner = {}
         for b in self.buckets:

@@ -252,7 +252,7 @@ class DFINETransformer(nn.Module):
         spec, out = self.spec, []
         for lvl, (h, w) in enumerate(spatial_shapes):
             gy, gx = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
-            xy = (torch.stack([gx, gy], -1).float() + 0.5) / torch.tensor([w, h], dtype=torch.float32, device=device)
+            xy = torch.stack([(gx.float() + 0.5) / float(w), (gy.float() + 0.5) / float(h)], -1)  # no host tensor: capturable
             wh = torch.full_like(xy, spec.anchor_grid * (2.0**lvl))
             out.append(torch.cat([xy, wh], -1).view(1, h * w, 4))
         anchors = torch.cat(out, 1)
@@ -267,15 +267,15 @@ class DFINETransformer(nn.Module):
 
     def _dn_attention_mask(self, max_gt, groups, device):
         """bool [Nd+Q, Nd+Q], True = blocked (arch/utils.py:437-455)."""
-        def make():
+        def make():  # built ON the device from index comparisons: a new (max_gt, groups) may first be seen inside a
+            # graph capture, where a host-built mask would be a pageable host->device copy on the capturing stream
             Q, Nd = self.spec.num_queries, 2 * max_gt * groups
-            m = torch.zeros(Nd + Q, Nd + Q, dtype=torch.bool)
-            m[Nd:, :Nd] = True
-            for g in range(groups):
-                lo, hi = 2 * max_gt * g, 2 * max_gt * (g + 1)
-                m[lo:hi, hi:Nd] = True
-                m[lo:hi, :lo] = True
-            return m.to(device)
+            idx = torch.arange(Nd + Q, device=device)
+            is_dn = idx < Nd
+            group = idx // (2 * max_gt)
+            row_dn, col_dn = is_dn[:, None], is_dn[None, :]
+            # matching queries cannot see denoising queries; a denoising group sees only itself (and the matching queries)
+            return (~row_dn & col_dn) | (row_dn & col_dn & (group[:, None] != group[None, :]))
         return self._cached(("dn_mask", max_gt, groups, str(device)), make)
 
     # ---------------------------------------------------------------- denoising queries

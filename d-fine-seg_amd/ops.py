@@ -24,20 +24,19 @@ class ZeroArena:
     """Pre-zeroed fp32 scratch handed out in slices: the fused ops need ~300 small zero-initialised
     workspaces per step (fp64 sum buffers, loss accumulators); one memset of the arena at the start of
     the step replaces one fill launch per workspace. ``ops.zero_arena`` is None unless a training loop
-    installs one; without it every workspace is its own ``torch.zeros``."""
+    installs one (``TrainStep`` owns its arena and installs it for the duration of its step); without it
+    every workspace is its own ``torch.zeros``."""
 
     def __init__(self, numel, device):
         self.buf = torch.zeros(numel, dtype=torch.float32, device=device)
         self.used = 0
-        self.high_water = 0
 
     def reset(self):
-        """Zero everything any earlier step touched and start handing out from the beginning. (Not just
-        the previous step's extent: inside a captured graph the memset length is frozen at capture time,
-        and steps of different kinds -- eager/captured, with/without masks -- use different amounts.)"""
-        self.high_water = max(self.high_water, self.used)
-        if self.high_water:
-            self.buf[: self.high_water].zero_()
+        """Zero the WHOLE arena and start handing out from the beginning. (Not just the extent earlier steps
+        used: inside a captured graph the memset length is frozen at capture time, and a step captured later
+        -- another ground-truth count, with masks -- may take more than any step before it; its tail would
+        then keep accumulating across replays. 32 MB of memset is ~7 us.)"""
+        self.buf.zero_()
         self.used = 0
 
     def take(self, n):

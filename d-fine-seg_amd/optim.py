@@ -174,7 +174,13 @@ class FusedAdamWEMA:
         self.exp_avg_sq = torch.zeros_like(flat.params)
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=flat.device)
         self.hyper = torch.zeros(_HYPER_LEN, dtype=torch.float32, device=flat.device)
-        self._hyper_host = torch.zeros(_HYPER_LEN, dtype=torch.float32).pin_memory() if flat.device.type == "cuda" else torch.zeros(_HYPER_LEN)
+        # per-step scalars travel through a small RING of pinned buffers: with graph replay the host enqueues a step in
+        # under a millisecond while the GPU takes tens, so a single staging buffer would be rewritten for step t+k before
+        # step t's async copy has read it; a slot is reused only after the copy that read it has completed (event)
+        on_gpu = flat.device.type == "cuda"
+        self._hyper_ring = [torch.zeros(_HYPER_LEN, dtype=torch.float32).pin_memory() if on_gpu else torch.zeros(_HYPER_LEN)
+                            for _ in range(8 if on_gpu else 1)]
+        self._hyper_events = [None] * len(self._hyper_ring)
         self._group_begin = (_lib.ctypes.c_longlong * len(flat.group_begin))(*flat.group_begin)
         self.t = 0
         self.ema_decay = -1.0
@@ -188,7 +194,10 @@ class FusedAdamWEMA:
     def _upload_scalars(self):
         """Advance the step counter and push this step's scalars (one pinned async copy)."""
         self.t += 1
-        h = self._hyper_host
+        slot = self.t % len(self._hyper_ring)
+        if self._hyper_events[slot] is not None:
+            self._hyper_events[slot].synchronize()  # the copy issued len(ring) steps ago
+        h = self._hyper_ring[slot]
         h[0] = self.clip if self.clip else -1.0
         h[1], h[2], h[3] = self.betas[0], self.betas[1], self.eps
         h[4], h[5] = 1.0 - self.betas[0] ** self.t, 1.0 - self.betas[1] ** self.t
@@ -196,6 +205,10 @@ class FusedAdamWEMA:
         for g, (lr, wd) in enumerate(zip(self.lrs, self.weight_decays)):
             h[_GROUP_OFF + 2 * g], h[_GROUP_OFF + 2 * g + 1] = lr, wd
         self.hyper.copy_(h, non_blocking=True)
+        if self.flat.device.type == "cuda":
+            ev = self._hyper_events[slot] or torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._hyper_events[slot] = ev
 
     def launch(self):
         """The device work of one step (graph-capturable: no host values are baked in)."""

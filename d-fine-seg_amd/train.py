@@ -83,7 +83,7 @@ class TrainStep:
     def __init__(self, model_name="m", num_classes=80, enable_mask_head=False, img_size=(640, 640),
                  device="cuda", base_lr=1.5e-4, backbone_lr=2e-5, betas=(0.9, 0.999), weight_decay=1.25e-4,
                  clip_max_norm=0.1, use_ema=True, ema_momentum=0.9998, amp=True, total_steps=10000,
-                 pct_start=0.1, grad_reducer=None, use_graph=True, graph_warmup=3, graph_masks=False):
+                 pct_start=0.1, grad_reducer=None, use_graph=True, graph_warmup=3, graph_masks=True):
         self.device = torch.device(device)
         self.num_classes = num_classes
         self.model = build_model(model_name, num_classes, enable_mask_head, self.device, img_size=list(img_size))
@@ -105,25 +105,48 @@ class TrainStep:
         if self.grad_reducer is not None:  # non-trainable state is not in the flat buffer: align it once
             for t in list(self.model.buffers()) + [p for p in self.model.parameters() if not p.requires_grad]:
                 torch.distributed.broadcast(t, src=0)
+            # the EMA copy was taken from this rank's own initial weights BEFORE the reducer broadcast rank 0's: re-seed it
+            # from the (now common) live weights and buffers so the averaged model is identical on every rank
+            self.sync_ema_to_model()
         self.use_graph = (use_graph and self.device.type == "cuda"
                           and (self.grad_reducer is None or getattr(self.grad_reducer, "graph_safe", False)))
         self.graph_warmup = graph_warmup
         self.graph_masks = graph_masks
         self._graphs = {}  # (batch, max_gt, has_gt) -> (graph, static images, static TargetBatch, static loss)
         self._conv_norms = [m for m in self.model.modules() if isinstance(m, ConvNorm)]
+        self.arena = None
         if self.device.type == "cuda":  # zero-initialised scratch for the fused ops: one memset per step
             from . import ops
 
-            ops.zero_arena = ops.ZeroArena(16 << 20, self.device)
+            self.arena = ops.ZeroArena(8 << 20, self.device)  # owned by this step: its graphs hold pointers into it
+        self._graph_pool = None   # every captured graph of this step shares one private memory pool
+        self.max_graphs = 16      # bounded: each distinct (shape, GT count) key is one graph
+        self.last_step_replayed = False  # whether the most recent step() replayed a captured graph
         self.model.train()
+
+    def sync_ema_to_model(self):
+        """EMA weights and float buffers := the live model's (used after a broadcast / checkpoint load)."""
+        if self.ema is None:
+            return
+        with torch.no_grad():
+            if self.optimizer.ema_flat is not None:
+                self.optimizer.ema_flat.copy_(self.flat.params)
+            live = dict(self.model.named_parameters())
+            for n, p in self.ema.model.named_parameters():
+                if not live[n].requires_grad:
+                    p.copy_(live[n])
+            live_b = dict(self.model.named_buffers())
+            for n, b in self.ema.model.named_buffers():
+                b.copy_(live_b[n])
 
     # ------------------------------------------------------------------ one step, device side
     def _forward_match(self, images, tb):
         """Model forward and the matchings; returns (outputs, criterion state) -- no collective inside."""
         from . import ops
 
-        if ops.zero_arena is not None:
-            ops.zero_arena.reset()
+        ops.zero_arena = self.arena  # this step's scratch (module-level handle: the ops are free functions)
+        if self.arena is not None:
+            self.arena.reset()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
             out = self.model(images, targets=tb)
         return out, self.criterion.match(out)  # fp32, outside autocast like train.py:548-549
@@ -167,16 +190,23 @@ class TrainStep:
         if tb.masks is not None:  # per-image resize of the GT masks to the mask-logit size: host loop, outside any capture
             s = self.model.decoder.spec.strides[0] // 2  # mask logits live at half the finest stride (ConvTranspose 2x2)
             tb.dense_mask_targets(images.shape[-2] // s, images.shape[-1] // s, self.device)
-        # segment task: the step with the mask branch is capturable by construction (dense, sync-free) and the
-        # captured D-FINE-n step replays to the eager losses (tests/test_optim.py), but both captured runs of
-        # D-FINE-m at batch 32 ended in a GPU memory-aperture fault after a few replays while the eager step
-        # with the same kernels is clean -- unexplained, so mask batches run eagerly unless ``graph_masks``
+        # segment task: the step with the mask branch is dense and sync-free like the detect step and is captured too
+        # (``graph_masks=False`` keeps mask batches eager). Round 1's captured D-FINE-m segment runs faulted inside ATen's
+        # embedding_dense_backward (its sort / unique-by-key scratch pipeline); the denoising embedding's
+        # backward is now one HIP kernel (ops.embedding) and that pipeline is no longer on the path
         if not self.use_graph or self.iters <= self.graph_warmup or (tb.mask_tgt is not None and not self.graph_masks):
+            self.last_step_replayed = False
             return self._body(images, tb)
         key = (tuple(images.shape), tb.max_gt, max(tb.num_gts), tb.total > 0, tb.mask_tgt is not None)
         entry = self._graphs.get(key)
         if entry is None:
-            entry = self._graphs[key] = self._capture(images, tb)
+            if len(self._graphs) >= self.max_graphs:  # drop the least recently used graph
+                self._graphs.pop(next(iter(self._graphs)))
+            entry = self._capture(images, tb)
+        else:
+            self._graphs.pop(key)
+        self._graphs[key] = entry  # most recently used last
+        self.last_step_replayed = True
         graph, s_images, s_tb, s_loss = entry
         s_images.copy_(images, non_blocking=True)
         s_tb.labels.copy_(tb.labels, non_blocking=True)
@@ -198,14 +228,19 @@ class TrainStep:
         s_tb = TargetBatch(tb.labels.clone(), tb.boxes.clone(), tb.valid.clone(), list(tb.num_gts), tb.counts.clone(), None,
                            tb.mask_tgt.clone() if tb.mask_tgt is not None else None)
         graph = torch.cuda.CUDAGraph()
+        pool_kw = {"pool": self._graph_pool} if self._graph_pool is not None else {}
         if self.grad_reducer is None:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, **pool_kw):
                 s_loss = self._body(s_images, s_tb)
+            if self._graph_pool is None:
+                self._graph_pool = graph.pool()
             return graph, s_images, s_tb, s_loss
         # data parallel: three graphs; the two collectives (2-float normaliser all-reduce of the criterion,
         # gradient all-reduce) run between their replays and are never part of a capture
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, **pool_kw):
             out, state = self._forward_match(s_images, s_tb)
+        if self._graph_pool is None:
+            self._graph_pool = graph.pool()
         middle = torch.cuda.CUDAGraph()
         with torch.cuda.graph(middle, pool=graph.pool()):
             s_loss = self._loss_backward(out, state)

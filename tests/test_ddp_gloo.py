@@ -119,6 +119,79 @@ def test_flat_allreduce_world2_gloo():
         assert dict(result) == {0: "ok", 1: "ok"}
 
 
+def _shadow_worker(rank, world, port, result):
+    """Ranks start from DIFFERENT weights with the bf16 shadow already built (TrainStep's order of construction): after
+    either reducer's broadcast the shadow the compute path reads must be bf16(rank 0's weights) on every rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dfine_seg_amd import ops
+
+        for make in (lambda f: BucketedGradReducer(f, num_buckets=2), lambda f: FlatGradAllReduce(f)):
+            torch.manual_seed(100 + rank)
+            model = Toy()
+            flat = FlatState(model)
+            flat.enable_bf16_shadow()
+            before = flat.shadow.clone()
+            make(flat)
+            ops.DIRECT_WGRAD_ACCUM = True
+            assert flat.bf16_shadow_is_current()
+            assert torch.equal(flat.shadow, flat.params.to(torch.bfloat16)), "shadow not refreshed after the broadcast"
+            assert torch.equal(ops.bf16_of(model.a.weight), model.a.weight.detach().to(torch.bfloat16))
+            gathered = [torch.zeros_like(flat.shadow) for _ in range(world)]
+            dist.all_gather(gathered, flat.shadow)
+            assert all(torch.equal(gathered[0], g) for g in gathered)
+            if rank > 0:
+                assert not torch.equal(before, flat.shadow)  # it really was this rank's own random init before
+        result[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_shadow_is_refreshed_by_the_reducers_broadcast_world2_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        result = mgr.dict()
+        mp.spawn(_shadow_worker, args=(world, _free_port(), result), nprocs=world, join=True)
+        assert dict(result) == {0: "ok", 1: "ok"}
+
+
+def _ema_worker(rank, world, port, result):
+    """TrainStep built under a process group from per-rank seeds: live weights, EMA weights and EMA buffers must all be
+    rank 0's on every rank (the EMA copy is taken before the reducer's broadcast and re-seeded after it)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dfine_seg_amd import ops
+        from dfine_seg_amd.train import TrainStep
+
+        torch.manual_seed(42 + rank)
+        t = TrainStep("n", 80, False, (320, 320), "cpu", grad_reducer=FlatGradAllReduce, use_graph=False, amp=True)
+        ops.DIRECT_WGRAD_ACCUM = True
+        if rank == 0:  # make the buffers differ too (running statistics)
+            pass
+        for name, tensor in [("params", t.flat.params), ("ema", t.optimizer.ema_flat)]:
+            gathered = [torch.zeros_like(tensor) for _ in range(world)]
+            dist.all_gather(gathered, tensor)
+            assert all(torch.equal(gathered[0], g) for g in gathered), f"{name} differ across ranks"
+        assert torch.equal(t.optimizer.ema_flat, t.flat.params)
+        assert torch.equal(t.flat.shadow, t.flat.params.to(torch.bfloat16))
+        live = dict(t.model.named_buffers())
+        for n, b in t.ema.model.named_buffers():
+            assert torch.equal(b, live[n]), n
+        result[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_step_ema_and_shadow_are_aligned_across_ranks_world2_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        result = mgr.dict()
+        mp.spawn(_ema_worker, args=(world, _free_port(), result), nprocs=world, join=True)
+        assert dict(result) == {0: "ok", 1: "ok"}
+
+
 def test_bucket_assignment_covers_every_trainable_parameter_once():
     model = Toy()
     buckets = assign_buckets(FlatState(model).entries, num_buckets=3, min_bucket_bytes=64)

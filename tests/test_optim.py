@@ -100,15 +100,18 @@ def test_fused_adamw_ema_matches_torch(hip_lib):
 
 
 @pytest.mark.gpu
-def test_graph_replay_matches_eager(hip_lib):
-    """The captured step must compute what the eager step computes (same weights, same batches)."""
+@pytest.mark.parametrize("amp", [False, True])
+def test_graph_replay_matches_eager(hip_lib, amp):
+    """The captured step must compute what the eager step computes (same weights, same batches); with ``amp`` the
+    benchmarked path (bf16 shadow weights, implicit-GEMM / wgrad kernels, direct accumulation) is what is replayed.
+    Tolerance: fp32 2e-3 (atomic summation order), bf16 2e-2."""
     from dfine_seg_amd.synth import synthetic_batch
     from dfine_seg_amd.train import TrainStep
 
     losses = {}
     for use_graph in (False, True):
         torch.manual_seed(0)
-        t = TrainStep("n", 80, False, (320, 320), "cuda", total_steps=100, use_graph=use_graph, graph_warmup=2, amp=False)
+        t = TrainStep("n", 80, False, (320, 320), "cuda", total_steps=100, use_graph=use_graph, graph_warmup=2, amp=amp)
         out = []
         for i in range(6):
             torch.manual_seed(100 + i)  # same denoising noise stream for both runs
@@ -116,8 +119,59 @@ def test_graph_replay_matches_eager(hip_lib):
             out.append(float(t.step(images, targets)))
         losses[use_graph] = out
         assert (len(t._graphs) == 1) == use_graph
+    tol = 2e-2 if amp else 2e-3
     for a, b in zip(losses[False], losses[True]):
-        assert abs(a - b) <= 2e-3 * abs(a), (losses[False], losses[True])
+        assert abs(a - b) <= tol * abs(a), (losses[False], losses[True])
+
+
+@pytest.mark.gpu
+def test_graph_replay_with_varying_ground_truth_counts(hip_lib):
+    """Real batches have a different maximum GT count almost every step: each new (padded width, max count) key is
+    captured on first sight, with NO eager pass for that key (the denoising attention mask and every other cached
+    constant must be built on the device), all graphs share one memory pool, and the losses must equal the eager
+    run's. bf16 path, 10 steps, GT counts 1..20 per image."""
+    from dfine_seg_amd.synth import synthetic_batch
+    from dfine_seg_amd.train import TrainStep
+
+    losses, n_graphs = {}, 0
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        t = TrainStep("n", 80, False, (320, 320), "cuda", total_steps=100, use_graph=use_graph, graph_warmup=2, amp=True)
+        out = []
+        for i in range(10):
+            torch.manual_seed(100 + i)
+            images, targets = synthetic_batch(2, 320, 320, 80, 4, seed=i, device="cuda", random_counts=True)
+            out.append(float(t.step(images, targets)))
+        losses[use_graph] = out
+        n_graphs = max(n_graphs, len(t._graphs))
+    assert n_graphs >= 4, n_graphs  # several distinct keys were captured after the warm-up
+    for a, b in zip(losses[False], losses[True]):
+        assert abs(a - b) <= 2e-2 * abs(a), (losses[False], losses[True])
+
+
+@pytest.mark.gpu
+def test_steps_without_host_sync_match_synced_steps(hip_lib):
+    """Graph replay lets the host run many steps ahead of the GPU: the per-step scalars (learning rates, Adam bias
+    corrections, EMA decay) must still reach the step they were computed for (ring of pinned staging buffers).
+    12 replayed steps with no synchronisation vs the same steps with a sync after each: same weights."""
+    from dfine_seg_amd.synth import synthetic_batch
+    from dfine_seg_amd.train import TrainStep
+
+    finals = []
+    images, targets = synthetic_batch(2, 320, 320, 80, 4, seed=3, device="cuda")
+    for sync_every_step in (True, False):
+        torch.manual_seed(0)
+        t = TrainStep("n", 80, False, (320, 320), "cuda", total_steps=20, pct_start=0.3, use_graph=True, graph_warmup=2, amp=False)
+        for i in range(14):
+            torch.manual_seed(100 + i)
+            loss = t.step(images, targets)
+            if sync_every_step:
+                float(loss)
+        torch.cuda.synchronize()
+        finals.append((t.flat.params.clone(), t.optimizer.exp_avg_sq.clone()))
+    # Adam's second moment is the most sensitive to a wrong bias correction / learning-rate slot
+    torch.testing.assert_close(finals[0][1], finals[1][1], rtol=1e-3, atol=1e-12)
+    torch.testing.assert_close(finals[0][0], finals[1][0], rtol=1e-3, atol=2e-5)
 
 
 @pytest.mark.gpu
@@ -152,7 +206,8 @@ def test_bf16_shadow_follows_the_master_weights(hip_lib):
 
 
 @pytest.mark.gpu
-def test_graph_replay_matches_eager_segment(hip_lib):
+@pytest.mark.parametrize("amp", [False, True])
+def test_graph_replay_matches_eager_segment(hip_lib, amp):
     """Same as above with the mask branch in the captured step (graph_masks=True): pixel decoder, mask
     embeddings, matched-rows mask logits and the dense focal/dice loss must replay to the eager losses."""
     from dfine_seg_amd.synth import synthetic_batch
@@ -161,7 +216,7 @@ def test_graph_replay_matches_eager_segment(hip_lib):
     losses = {}
     for use_graph in (False, True):
         torch.manual_seed(0)
-        t = TrainStep("n", 80, True, (320, 320), "cuda", total_steps=100, use_graph=use_graph, graph_warmup=2, amp=False,
+        t = TrainStep("n", 80, True, (320, 320), "cuda", total_steps=100, use_graph=use_graph, graph_warmup=2, amp=amp,
                       graph_masks=True)
         out = []
         for i in range(5):
@@ -170,5 +225,6 @@ def test_graph_replay_matches_eager_segment(hip_lib):
             out.append(float(t.step(images, targets)))
         losses[use_graph] = out
         assert (len(t._graphs) == 1) == use_graph
+    tol = 2e-2 if amp else 2e-3
     for a, b in zip(losses[False], losses[True]):
-        assert abs(a - b) <= 2e-3 * abs(a), (losses[False], losses[True])
+        assert abs(a - b) <= tol * abs(a), (losses[False], losses[True])
