@@ -181,6 +181,8 @@ class PackedSelfAttention(nn.Module):
         H, dh = self.n_head, D // self.n_head
         qk = ops.linear(qk_in, self.in_proj_weight, self.in_proj_bias, 0, 2 * D)
         v = ops.linear(v_in, self.in_proj_weight, self.in_proj_bias, 2 * D, 3 * D)
+        if ops.self_attention_supported(qk, v, H):  # HIP: reads q / k / v where the projections left them, no head permutes
+            return self.out_proj(ops.self_attention(qk, v, blocked, H))
         q, k = qk.view(B, L, 2, H, dh).permute(2, 0, 3, 1, 4)
         v = v.view(B, L, H, dh).transpose(1, 2)
         allowed = None if blocked is None else ~blocked

@@ -912,6 +912,63 @@ def dense_conv(x, weight, stride=1, padding=0, pad_br=None, stats=None, out=None
     return _DenseConv.apply(x, weight, int(stride), int(padding), pad_br, stats, out)
 
 
+class _SelfAttention(torch.autograd.Function):
+    """softmax(scale * Q K^T + mask) V on the projections' own layout; see include/dfine_hip.h (dfine_attention_*)."""
+
+    @staticmethod
+    def forward(ctx, qk, v, blocked, n_head):
+        _lib.require_gpu(qk, v)
+        lib = _lib.load()
+        B, L, D2 = qk.shape
+        D = D2 // 2
+        dh = D // n_head
+        qk, v = qk.contiguous(), v.contiguous()
+        k_view = qk[..., D:]
+        mask = blocked.view(torch.uint8).contiguous() if blocked is not None else None
+        o = torch.empty(B, L, D, dtype=torch.bfloat16, device=qk.device)
+        lse = torch.empty(B, n_head, L, dtype=torch.float32, device=qk.device)
+        scale = 1.0 / dh ** 0.5
+        with _lib.timed("attention_fwd", (3 * B * L * D + B * L * D) * 2, f"B{B} L{L} H{n_head} dh{dh}"):
+            rc = lib.dfine_attention_fwd(_lib.ptr(qk), _lib.ptr(k_view), _lib.ptr(v), D2, D2, D, _lib.ptr(mask), _lib.ptr(o), D,
+                                         _lib.ptr(lse), B, n_head, L, dh, scale, _lib.stream_ptr())
+        _lib.check(rc, "dfine_attention_fwd")
+        ctx.save_for_backward(qk, v, o, lse, mask)
+        ctx.meta = (n_head, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        qk, v, o, lse, mask = ctx.saved_tensors
+        n_head, scale = ctx.meta
+        lib = _lib.load()
+        B, L, D2 = qk.shape
+        D = D2 // 2
+        dh = D // n_head
+        go = go.to(torch.bfloat16).contiguous()
+        dqk = torch.empty_like(qk)
+        dv = torch.empty_like(v)
+        dsum = torch.empty_like(lse)
+        with _lib.timed("attention_bwd", 8 * B * L * D * 2, f"B{B} L{L} H{n_head} dh{dh}"):
+            rc = lib.dfine_attention_bwd(_lib.ptr(qk), _lib.ptr(qk[..., D:]), _lib.ptr(v), D2, D2, D, _lib.ptr(mask), _lib.ptr(o), D,
+                                         _lib.ptr(lse), _lib.ptr(go), D, _lib.ptr(dqk), D2, _lib.ptr(dqk[..., D:]), D2, _lib.ptr(dv), D,
+                                         _lib.ptr(dsum), B, n_head, L, dh, scale, _lib.stream_ptr())
+        _lib.check(rc, "dfine_attention_bwd")
+        return dqk, dv, None, None
+
+
+def self_attention_supported(qk, v, n_head):
+    D = v.shape[-1]
+    return (qk.is_cuda and qk.dtype == torch.bfloat16 and v.dtype == torch.bfloat16 and D % n_head == 0
+            and (D // n_head) % 8 == 0 and D // n_head <= 64 and qk.shape[-1] == 2 * D)
+
+
+def self_attention(qk, v, blocked, n_head):
+    """qk [B, L, 2D] bf16 (query projection in columns [0, D), key projection in [D, 2D)), v [B, L, D] bf16, ``blocked``
+    bool [L, L] (True = may not attend) or None -> softmax(q k^T / sqrt(dh) + mask) v as [B, L, D] bf16, heads interleaved
+    the way nn.MultiheadAttention's out_proj expects. HIP forward and backward (csrc/attention.hip)."""
+    return _SelfAttention.apply(qk, v, blocked, int(n_head))
+
+
 class _ConvTranspose2x2(torch.autograd.Function):
     """nn.ConvTranspose2d(kernel 2, stride 2, no bias) on a channels_last map: forward = four 1-tap implicit-GEMM
     launches writing interleaved output pixels, input gradient = one 4-tap stride-2 gather, weight gradient = the

@@ -93,9 +93,11 @@ class TrainStep:
         if amp:
             self.flat.enable_bf16_shadow()
         ema_flat = self.flat.mirror(self.ema.model) if self.ema is not None else None
-        # groups and max learning rates as in train.py:184-208 (OneCycle peaks at 2x the configured lr)
-        self.max_lrs = {"backbone": backbone_lr * 2, "backbone_norm": backbone_lr * 2,
-                        "encdec_norm_bias": base_lr * 2, "rest": base_lr * 2}
+        # groups and max learning rates as in train.py:184-208: OneCycle peaks at 2x the configured lr -- per group
+        # (backbone groups at 2*backbone_lr) only for the l / x sizes; for n / s / m the reference passes the SCALAR
+        # max_lr = 2*base_lr, which OneCycleLR applies to all four groups, backbone included
+        bb_max = backbone_lr * 2 if model_name in ("l", "x") else base_lr * 2
+        self.max_lrs = {"backbone": bb_max, "backbone_norm": bb_max, "encdec_norm_bias": base_lr * 2, "rest": base_lr * 2}
         wds = {"backbone": weight_decay, "backbone_norm": 0.0, "encdec_norm_bias": 0.0, "rest": weight_decay}
         self.optimizer = FusedAdamWEMA(self.flat, self.max_lrs, wds, betas=betas, clip_max_norm=clip_max_norm, ema_flat=ema_flat)
         self.total_steps, self.pct_start = total_steps, pct_start
@@ -140,7 +142,7 @@ class TrainStep:
                 b.copy_(live_b[n])
 
     # ------------------------------------------------------------------ one step, device side
-    def _forward_match(self, images, tb):
+    def _forward_match(self, images, tb, inject=None):
         """Model forward and the matchings; returns (outputs, criterion state) -- no collective inside."""
         from . import ops
 
@@ -148,17 +150,18 @@ class TrainStep:
         if self.arena is not None:
             self.arena.reset()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
-            out = self.model(images, targets=tb)
+            out = self.model(images, targets=tb, inject=inject)
         return out, self.criterion.match(out)  # fp32, outside autocast like train.py:548-549
 
     def _loss_backward(self, out, state):
         losses = self.criterion.compute_losses(out, state)
+        self.last_losses = {k: v.detach() for k, v in losses.items()}  # the reference's loss dict of this step (device scalars)
         loss = torch.stack(list(losses.values())).sum()  # one reduction instead of a chain of ~50 adds
         loss.backward()
         return loss.detach()
 
-    def _forward_backward(self, images, tb):
-        out, state = self._forward_match(images, tb)
+    def _forward_backward(self, images, tb, inject=None):
+        out, state = self._forward_match(images, tb, inject)
         self.criterion.reduce_normalisers(state)  # the criterion's one collective (2 floats)
         return self._loss_backward(out, state)
 
@@ -167,8 +170,8 @@ class TrainStep:
         if self.ema is not None:
             self.ema.update_buffers(self.optimizer.hyper[6])
 
-    def _body(self, images, tb):
-        loss = self._forward_backward(images, tb)
+    def _body(self, images, tb, inject=None):
+        loss = self._forward_backward(images, tb, inject)
         if self.grad_reducer is not None:
             self.grad_reducer.finish()
         self._optimizer_tail()
@@ -181,7 +184,22 @@ class TrainStep:
         self.optimizer.set_schedule(lrs, decay)
         self.optimizer._upload_scalars()
 
-    def step(self, images, targets):
+    @staticmethod
+    def _inject_leaves(inject):
+        """(key path, tensor) pairs of an ``inject`` dict ({"topk_ind": t, "cdn_noise": {name: t}}) in a fixed order."""
+        leaves = []
+        for k in sorted(inject or {}):
+            v = inject[k]
+            if isinstance(v, dict):
+                leaves += [((k, kk), v[kk]) for kk in sorted(v)]
+            elif v is not None:
+                leaves.append(((k,), v))
+        return leaves
+
+    def step(self, images, targets, inject=None):
+        """``inject`` (parity runs): {"topk_ind": int64 [B, Q], "cdn_noise": {...}} replaces the query selection and the
+        denoising noise of this step (see DFINETransformer.forward); under graph replay its tensors are copied into static
+        buffers like the images and targets."""
         tb = TargetBatch.from_list(targets, self.num_classes, self.device)
         images = images.to(self.device, non_blocking=True)
         self._schedule()
@@ -196,18 +214,22 @@ class TrainStep:
         # backward is now one HIP kernel (ops.embedding) and that pipeline is no longer on the path
         if not self.use_graph or self.iters <= self.graph_warmup or (tb.mask_tgt is not None and not self.graph_masks):
             self.last_step_replayed = False
-            return self._body(images, tb)
-        key = (tuple(images.shape), tb.max_gt, max(tb.num_gts), tb.total > 0, tb.mask_tgt is not None)
+            return self._body(images, tb, inject)
+        leaves = self._inject_leaves(inject)
+        key = (tuple(images.shape), tb.max_gt, max(tb.num_gts), tb.total > 0, tb.mask_tgt is not None,
+               tuple((path, tuple(t.shape)) for path, t in leaves))
         entry = self._graphs.get(key)
         if entry is None:
             if len(self._graphs) >= self.max_graphs:  # drop the least recently used graph
                 self._graphs.pop(next(iter(self._graphs)))
-            entry = self._capture(images, tb)
+            entry = self._capture(images, tb, inject)
         else:
             self._graphs.pop(key)
         self._graphs[key] = entry  # most recently used last
         self.last_step_replayed = True
-        graph, s_images, s_tb, s_loss = entry
+        graph, s_images, s_tb, s_loss, s_leaves = entry
+        for (_, dst), (_, src) in zip(s_leaves, leaves):
+            dst.copy_(src, non_blocking=True)
         s_images.copy_(images, non_blocking=True)
         s_tb.labels.copy_(tb.labels, non_blocking=True)
         s_tb.boxes.copy_(tb.boxes, non_blocking=True)
@@ -220,25 +242,34 @@ class TrainStep:
             m._pending_batches += 1
         return s_loss
 
-    def _capture(self, images, tb):
+    def _capture(self, images, tb, inject=None):
         """Capture the step for this (batch shape, padded GT width, max GT count). The per-image GT
         counts inside may vary between replays; the maximum (it fixes the number of denoising
         queries) may not -- a new maximum gets its own graph."""
         s_images = images.clone()
         s_tb = TargetBatch(tb.labels.clone(), tb.boxes.clone(), tb.valid.clone(), list(tb.num_gts), tb.counts.clone(), None,
                            tb.mask_tgt.clone() if tb.mask_tgt is not None else None)
+        s_leaves = [(path, t.to(self.device).clone()) for path, t in self._inject_leaves(inject)]
+        s_inject = None
+        if s_leaves:
+            s_inject = {}
+            for path, t in s_leaves:
+                if len(path) == 1:
+                    s_inject[path[0]] = t
+                else:
+                    s_inject.setdefault(path[0], {})[path[1]] = t
         graph = torch.cuda.CUDAGraph()
         pool_kw = {"pool": self._graph_pool} if self._graph_pool is not None else {}
         if self.grad_reducer is None:
             with torch.cuda.graph(graph, **pool_kw):
-                s_loss = self._body(s_images, s_tb)
+                s_loss = self._body(s_images, s_tb, s_inject)
             if self._graph_pool is None:
                 self._graph_pool = graph.pool()
-            return graph, s_images, s_tb, s_loss
+            return graph, s_images, s_tb, s_loss, s_leaves
         # data parallel: three graphs; the two collectives (2-float normaliser all-reduce of the criterion,
         # gradient all-reduce) run between their replays and are never part of a capture
         with torch.cuda.graph(graph, **pool_kw):
-            out, state = self._forward_match(s_images, s_tb)
+            out, state = self._forward_match(s_images, s_tb, s_inject)
         if self._graph_pool is None:
             self._graph_pool = graph.pool()
         middle = torch.cuda.CUDAGraph()
@@ -248,4 +279,4 @@ class TrainStep:
         with torch.cuda.graph(tail, pool=graph.pool()):
             self._optimizer_tail()
         reduce_norm = lambda: self.criterion.reduce_normalisers(state)
-        return _SplitGraph(graph, reduce_norm, middle, self.grad_reducer, tail), s_images, s_tb, s_loss
+        return _SplitGraph(graph, reduce_norm, middle, self.grad_reducer, tail), s_images, s_tb, s_loss, s_leaves

@@ -369,6 +369,50 @@ int dfine_transpose_weights(const void* src /* bf16 */, void* dst /* bf16 */, co
 int dfine_embedding_wgrad(const long long* idx, const void* g, int dtype, float* dW, long long M, int D, int rows,
                           int padding_idx, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Multi-head self-attention  O = softmax(scale * Q K^T + mask) V  per (image, head), forward and backward.
+ * Replaces nn.MultiheadAttention's attention core at both sites of the path: decoder self-attention with the
+ * denoising mask (reference src/d_fine/arch/dfine_decoder.py:233-240, need_weights slow path materialising
+ * [B, 8, Lq, Lq]) and the AIFI layer (hybrid_encoder.py:243-290).
+ *   q, k, v: bf16 row-major [B*L, >= H*dh] with row pitches ldq / ldk / ldv (q and k are typically the two halves of
+ *   ONE [B*L, 2D] projection output: k = q + D, ldq = ldk = 2D); head h = columns [h*dh, (h+1)*dh). 16-byte
+ *   aligned bases, pitches % 8 == 0, dh in {8..64} and a multiple of 8.
+ *   blocked: u8 [L, L] (row = query, nonzero = may NOT attend), shared by all images and heads, or NULL.
+ *   o: bf16 [B*L, ...] pitch ldo (written); lse: f32 [B, H, L] = log2-domain log-sum-exp of the scaled scores
+ *   (-inf for a row with every key blocked, whose output is 0).
+ * Backward: dout bf16 pitch lddo -> dq, dk, dv bf16 with their own pitches (dq / dk may be the halves of one
+ *   [B*L, 2D] buffer), all written; dsum f32 [B, H, L] is scratch (rowsum(dO * O)). No atomics: results are
+ *   bitwise reproducible.
+ * ------------------------------------------------------------------------------------- */
+int dfine_attention_fwd(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
+                        const unsigned char* blocked, void* o, int ldo, float* lse, int B, int H, int L, int dh,
+                        float scale, void* stream);
+int dfine_attention_bwd(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
+                        const unsigned char* blocked, const void* o, int ldo, const float* lse, const void* dout,
+                        int lddo, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, float* dsum, int B,
+                        int H, int L, int dh, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Evaluation post-processing (reference src/dl/train.py:227-319 Trainer.preds_postprocess with
+ * use_focal_loss=True; helpers src/dl/utils.py:160-183, 623-672, 715-789).
+ * dfine_postprocess_topk: per image the K best of the Q*C sigmoid scores, descending (ties: lower flat index
+ *   first), with label = idx % C, query = idx / C and that query's box mapped to the ORIGINAL image: cxcywh in [0,1]
+ *   -> absolute xyxy on the network input (floor / ceil, clamped to [1, size-1]: norm_xywh_to_abs_xyxy) -> original
+ *   size (scale_boxes, or scale_boxes_ratio_kept with the letterbox padding removed and clipping when keep_ratio).
+ *   logits [B, Q, C] f32 or bf16 (dtype), boxes f32 [B, Q, 4], orig_sizes int64 [B, 2] (h, w) ->
+ *   scores f32 [B, K], labels int64 [B, K], qidx int64 [B, K], out_boxes f32 [B, K, 4]. K <= 512.
+ * dfine_postprocess_masks (one image): probs [Q, Hm, Wm] f32 or bf16 = that image's sigmoid mask maps, qidx int64
+ *   [n_inst] the kept queries, boxes f32 [n_inst, 4] their xyxy boxes in original-image pixels -> out u8
+ *   [n_inst, H0, W0]: process_masks' two bilinear resizes in fp16 (mask grid -> network input, letterbox crop when
+ *   keep_ratio, -> original size), clamp, >= thresh, and cleanup_masks' "zero outside the box".
+ * ------------------------------------------------------------------------------------- */
+int dfine_postprocess_topk(const void* logits, int dtype, const float* boxes, const long long* orig_sizes, float* scores,
+                           long long* labels, long long* qidx, float* out_boxes, int B, int Q, int C, int K, int proc_h,
+                           int proc_w, int keep_ratio, void* stream);
+int dfine_postprocess_masks(const void* probs, int dtype, const long long* qidx, const float* boxes, unsigned char* out,
+                            int n_inst, int Hm, int Wm, int proc_h, int proc_w, int H0, int W0, int keep_ratio, float thresh,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

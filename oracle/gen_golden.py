@@ -228,7 +228,162 @@ def gen_model(names=None):
         save(fname, **out)
 
 
-GROUPS = {"msda": gen_msda, "model": gen_model}
+def import_reference_dl():
+    """Make ``src.dl.train`` / ``src.dl.utils`` importable for the two pieces of it that are on the path and need none
+    of its absent third-party imports: ``Trainer.preds_postprocess`` (+ process_boxes / process_masks / cleanup_masks)
+    and the optimizer-step recipe. hydra, omegaconf, wandb, cv2, albumentations, faster_coco_eval and torchmetrics are
+    not installed here; they are replaced by INERT placeholder modules (every attribute is a do-nothing object) whose
+    only job is to let the ``import`` statements at the top of those files succeed -- nothing that is executed for a
+    fixture touches them."""
+    import importlib.abc
+    import importlib.machinery
+
+    import_reference()
+    if "src.dl.train" in sys.modules:
+        return
+    absent = ("hydra", "omegaconf", "wandb", "cv2", "albumentations", "faster_coco_eval", "torchmetrics", "pycocotools")
+
+    class _Inert:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return a[0] if (len(a) == 1 and callable(a[0]) and not k) else _Inert()  # also usable as a decorator
+
+        def __getattr__(self, n):
+            return _Inert()
+
+        def __mro_entries__(self, bases):
+            return (object,)
+
+    class _InertModule(types.ModuleType):
+        def __getattr__(self, n):
+            if n.startswith("__"):
+                raise AttributeError(n)
+            return _Inert()
+
+    class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        def find_spec(self, name, path, target=None):
+            if name.split(".")[0] in absent:
+                return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+        def create_module(self, spec):
+            m = _InertModule(spec.name)
+            m.__path__ = []
+            return m
+
+        def exec_module(self, m):
+            pass
+
+    sys.meta_path.insert(0, _Finder())
+    sys.modules["torchvision.ops"].box_iou = None  # imported by name in validator.py, never called here
+    sys.modules["torchvision.ops"].nms = None
+    import src.dl.train  # noqa: F401
+
+
+def gen_postprocess(names=None):
+    """Trainer.preds_postprocess (src/dl/train.py:227-319) on seeded predictions: detection only and with masks, with and
+    without letterbox (keep_ratio), non-square original sizes."""
+    import_reference_dl()
+    from src.dl.train import Trainer
+
+    g = torch.Generator().manual_seed(11)
+    B, Q, C, Hm, Wm, proc = 2, 60, 7, 40, 40, (160, 160)
+    logits = torch.randn(B, Q, C, generator=g) * 2.0 - 1.0
+    cxcy = torch.rand(B, Q, 2, generator=g) * 0.7 + 0.15
+    wh = torch.rand(B, Q, 2, generator=g) * 0.3 + 0.05
+    boxes = torch.cat([cxcy, wh], -1)
+    # smooth blobs as mask probabilities (so the bilinear resizes are exercised away from 0/1 plateaus)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, Hm), torch.linspace(0, 1, Wm), indexing="ij")
+    d2 = (xx[None, None] - cxcy[..., 0, None, None]) ** 2 / (wh[..., 0, None, None] ** 2) + (yy[None, None] - cxcy[..., 1, None, None]) ** 2 / (wh[..., 1, None, None] ** 2)
+    masks = torch.sigmoid(4.0 * (0.3 - d2) + 0.3 * torch.randn(B, Q, Hm, Wm, generator=g))
+    orig_sizes = torch.tensor([[120, 90], [64, 100]])
+    inputs = torch.zeros(B, 3, *proc)
+    out = {"logits": logits, "boxes": boxes, "masks": masks, "orig_sizes": orig_sizes, "proc": np.array(proc), "num_top_queries": np.array(25),
+           "conf_thresh": np.array(0.5)}
+    for keep_ratio in (False, True):
+        for with_masks in (False, True):
+            outputs = {"pred_logits": logits.clone(), "pred_boxes": boxes.clone()}
+            if with_masks:
+                outputs["pred_masks"] = masks.clone()
+            res = Trainer.preds_postprocess(inputs, outputs, orig_sizes, C, keep_ratio, 0.5, num_top_queries=25)
+            tag = f"kr{int(keep_ratio)}.m{int(with_masks)}"
+            for b, r in enumerate(res):
+                for k, v in r.items():
+                    out[f"{tag}.{b}.{k}"] = v
+    save("postprocess", **out)
+
+
+STEP_CASE = dict(size="n", img=320, n_gts=[3, 5], base_lr=0.0008, backbone_lr=0.0004, betas=(0.9, 0.999), weight_decay=0.000125,
+                 clip=0.1, ema_momentum=0.9998, total_steps=10, pct_start=0.3, steps=2)
+
+
+def gen_step(names=None):
+    """Two optimizer steps exactly as the reference's hot loop runs them in fp32 (src/dl/train.py:488-511,545-560 with
+    amp off: forward, criterion, backward, clip_grad_norm_(0.1), AdamW over build_optimizer's four groups, OneCycleLR
+    with the scalar max_lr = 2*base_lr the n/s/m sizes get (:193-208), zero_grad, ModelEMA.update (:61-72))."""
+    import_reference_dl()
+    from copy import deepcopy
+
+    from src.d_fine import configs as ref_configs
+    from src.d_fine.dfine import build_loss, build_model, build_optimizer
+    from src.dl.train import ModelEMA
+    from torch.optim.lr_scheduler import OneCycleLR
+
+    from . import weights
+
+    c = STEP_CASE
+    torch.manual_seed(0)
+    model = build_model(c["size"], 80, False, "cpu", img_size=[c["img"], c["img"]], pretrained_model_path=None)
+    model.load_state_dict(weights.fill_state_dict(model.state_dict()), strict=True)
+    x = weights.synthetic_images(len(c["n_gts"]), c["img"], c["img"], SEED_WEIGHTS_IMG)
+    targets = weights.synthetic_targets(c["n_gts"], 80, SEED_TARGETS, with_masks=False, height=c["img"], width=c["img"])
+    ref_configs.models[c["size"]]["DFINECriterion"]["losses"] = ["vfl", "boxes", "local"]
+    crit = build_loss(c["size"], 80, 0.0, False)
+    opt = build_optimizer(model, lr=c["base_lr"], backbone_lr=c["backbone_lr"], betas=c["betas"], weight_decay=c["weight_decay"], base_lr=c["base_lr"])
+    sched = OneCycleLR(opt, max_lr=c["base_lr"] * 2, epochs=1, steps_per_epoch=c["total_steps"], pct_start=c["pct_start"], cycle_momentum=False)
+    ema = ModelEMA(model, c["ema_momentum"])
+    grabbed = {}
+    model.decoder.enc_score_head.register_forward_hook(lambda m, i, o: grabbed.__setitem__("enc_logits", o))
+    model.train()
+    p0 = {n: p.detach().clone() for n, p in model.named_parameters()}
+    out = {k: np.array(v) for k, v in c.items() if k not in ("size",)}
+    out["size"] = np.array(c["size"])
+    g = torch.Generator().manual_seed(5)
+    names_ = [n for n, p in model.named_parameters() if p.requires_grad]
+    sample_idx = {n: torch.randint(0, p0[n].numel(), (min(64, p0[n].numel()),), generator=g) for n in names_}
+    out["param.names"] = np.array(names_)
+    for s in range(c["steps"]):
+        torch.manual_seed(SEED_CDN + s)
+        res = model(x, targets=targets)
+        out[f"step{s}.topk_ind"] = torch.topk(grabbed["enc_logits"].max(-1).values, 300, dim=-1).indices
+        losses = crit(res, targets)
+        out[f"step{s}.loss.names"] = np.array(list(losses.keys()))
+        out[f"step{s}.loss.values"] = torch.stack([v.detach().float().reshape(()) for v in losses.values()])
+        sum(losses.values()).backward()
+        out[f"step{s}.lrs"] = np.array([g_["lr"] for g_ in opt.param_groups])
+        out[f"step{s}.grad_norm"] = torch.nn.utils.clip_grad_norm_(model.parameters(), c["clip"])
+        opt.step()
+        sched.step()
+        opt.zero_grad()
+        ema.update(s + 1, model)
+        cur = dict(model.named_parameters())
+        out[f"step{s}.param.norm"] = torch.stack([cur[n].detach().double().norm() for n in names_])
+        out[f"step{s}.delta.sample"] = torch.cat([(cur[n].detach() - p0[n]).flatten()[sample_idx[n]] for n in names_])
+    out["sample.index"] = torch.cat([sample_idx[n] for n in names_])
+    out["sample.count"] = np.array([sample_idx[n].numel() for n in names_])
+    ema_p = dict(ema.model.named_parameters())
+    out["ema.param.norm"] = torch.stack([ema_p[n].detach().double().norm() for n in names_])
+    out["ema.delta.sample"] = torch.cat([(ema_p[n].detach() - p0[n]).flatten()[sample_idx[n]] for n in names_])
+    bufs = {k: v for k, v in model.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
+    out["buffer.names"] = np.array(list(bufs.keys()))
+    out["buffer.norm"] = torch.stack([v.double().norm() for v in bufs.values()])
+    ema_sd = ema.model.state_dict()
+    out["ema.buffer.norm"] = torch.stack([ema_sd[k].double().norm() for k in bufs])
+    save("step_n320", **out)
+
+
+GROUPS = {"msda": gen_msda, "model": gen_model, "postprocess": gen_postprocess, "step": gen_step}
 
 
 def main(argv):

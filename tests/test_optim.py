@@ -99,8 +99,66 @@ def test_fused_adamw_ema_matches_torch(hip_lib):
             torch.testing.assert_close(e, r, rtol=2e-5, atol=1e-6)
 
 
+def _snapshot(t):
+    st = {"params": t.flat.params.clone(), "m": t.optimizer.exp_avg.clone(), "v": t.optimizer.exp_avg_sq.clone(),
+          "ema": t.optimizer.ema_flat.clone() if t.optimizer.ema_flat is not None else None,
+          "buffers": [b.clone() for b in t.model.buffers()], "ema_buffers": [b.clone() for b in t.ema.model.buffers()],
+          "t": t.optimizer.t, "iters": t.iters}
+    return st
+
+
+def _restore(t, st):
+    with torch.no_grad():
+        t.flat.params.copy_(st["params"]); t.flat.grads.zero_()
+        t.optimizer.exp_avg.copy_(st["m"]); t.optimizer.exp_avg_sq.copy_(st["v"])
+        if st["ema"] is not None:
+            t.optimizer.ema_flat.copy_(st["ema"])
+        for b, s in zip(t.model.buffers(), st["buffers"]):
+            b.copy_(s)
+        for b, s in zip(t.ema.model.buffers(), st["ema_buffers"]):
+            b.copy_(s)
+    t.optimizer.t, t.iters = st["t"], st["iters"]
+    t.flat.refresh_bf16_shadow()
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("amp", [False, True])
+@pytest.mark.parametrize("task", ["detect", "segment"])
+def test_captured_bf16_step_equals_eager_step_from_the_same_state(hip_lib, task):
+    """The BENCHMARKED path -- bf16 autocast, bf16 (+ transposed) shadow weights, implicit-GEMM / attention / wgrad
+    kernels accumulating straight into the flat fp32 gradients, fused optimizer, replayed as a hipGraph -- against the
+    same step run eagerly FROM THE SAME STATE (weights, moments, EMA, BatchNorm statistics, step counters, RNG seed), so
+    the two differ only by the order of float atomics inside one step: loss within 2e-3, updated weights within 1e-3
+    relative L2 (an Adam step moves a weight by ~lr whatever the gradient's size, so sign flips of tiny gradients are the
+    only amplification), Adam second moment within 2e-2."""
+    from dfine_seg_amd.synth import synthetic_batch
+    from dfine_seg_amd.train import TrainStep
+
+    seg = task == "segment"
+    torch.manual_seed(0)
+    t = TrainStep("n", 80, seg, (320, 320), "cuda", total_steps=100, use_graph=True, graph_warmup=2, amp=True)
+    for i in range(2):  # eager warm-up steps (also move the weights off their initial values)
+        torch.manual_seed(100 + i)
+        t.step(*synthetic_batch(2, 320, 320, 80, 4, with_masks=seg, seed=i, device="cuda"))
+    batch = synthetic_batch(2, 320, 320, 80, 4, with_masks=seg, seed=7, device="cuda")
+    snap = _snapshot(t)
+    results = []
+    for mode in ("eager", "capture+replay", "replay"):
+        _restore(t, snap)
+        t.use_graph = mode != "eager"
+        torch.manual_seed(200)
+        loss = float(t.step(*batch))
+        assert t.last_step_replayed == (mode != "eager")
+        results.append((loss, t.flat.params.clone(), t.optimizer.exp_avg_sq.clone()))
+    assert len(t._graphs) == 1
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    for loss, params, v in results[1:]:
+        assert abs(loss - results[0][0]) <= 2e-3 * abs(results[0][0]), [r[0] for r in results]
+        assert rel(params, results[0][1]) < 1e-3, rel(params, results[0][1])
+        assert rel(v, results[0][2]) < 2e-2, rel(v, results[0][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("amp", [False])
 def test_graph_replay_matches_eager(hip_lib, amp):
     """The captured step must compute what the eager step computes (same weights, same batches); with ``amp`` the
     benchmarked path (bf16 shadow weights, implicit-GEMM / wgrad kernels, direct accumulation) is what is replayed.
@@ -125,18 +183,20 @@ def test_graph_replay_matches_eager(hip_lib, amp):
 
 
 @pytest.mark.gpu
-def test_graph_replay_with_varying_ground_truth_counts(hip_lib):
+@pytest.mark.parametrize("amp", [False, True])
+def test_graph_replay_with_varying_ground_truth_counts(hip_lib, amp):
     """Real batches have a different maximum GT count almost every step: each new (padded width, max count) key is
     captured on first sight, with NO eager pass for that key (the denoising attention mask and every other cached
     constant must be built on the device), all graphs share one memory pool, and the losses must equal the eager
-    run's. bf16 path, 10 steps, GT counts 1..20 per image."""
+    run's. 10 steps, GT counts 1..20 per image; fp32 within 5e-3 (atomic summation order over 10 optimizer steps), the
+    bf16 path within 5e-2 (its round-off makes the two trajectories drift apart faster)."""
     from dfine_seg_amd.synth import synthetic_batch
     from dfine_seg_amd.train import TrainStep
 
     losses, n_graphs = {}, 0
     for use_graph in (False, True):
         torch.manual_seed(0)
-        t = TrainStep("n", 80, False, (320, 320), "cuda", total_steps=100, use_graph=use_graph, graph_warmup=2, amp=True)
+        t = TrainStep("n", 80, False, (320, 320), "cuda", total_steps=100, use_graph=use_graph, graph_warmup=2, amp=amp)
         out = []
         for i in range(10):
             torch.manual_seed(100 + i)
@@ -145,33 +205,47 @@ def test_graph_replay_with_varying_ground_truth_counts(hip_lib):
         losses[use_graph] = out
         n_graphs = max(n_graphs, len(t._graphs))
     assert n_graphs >= 4, n_graphs  # several distinct keys were captured after the warm-up
+    tol = 5e-2 if amp else 5e-3
     for a, b in zip(losses[False], losses[True]):
-        assert abs(a - b) <= 2e-2 * abs(a), (losses[False], losses[True])
+        assert abs(a - b) <= tol * abs(a), (losses[False], losses[True])
 
 
 @pytest.mark.gpu
 def test_steps_without_host_sync_match_synced_steps(hip_lib):
     """Graph replay lets the host run many steps ahead of the GPU: the per-step scalars (learning rates, Adam bias
-    corrections, EMA decay) must still reach the step they were computed for (ring of pinned staging buffers).
-    12 replayed steps with no synchronisation vs the same steps with a sync after each: same weights."""
-    from dfine_seg_amd.synth import synthetic_batch
-    from dfine_seg_amd.train import TrainStep
+    corrections, EMA decay) must still reach the step they were computed for (ring of pinned staging buffers with an
+    event per slot). 20 optimizer steps are enqueued behind a kernel that blocks the GPU, so the host has written ALL
+    their scalars before the first step runs; the result must equal, bit for bit, the run that synchronises after
+    every step (the update kernels are deterministic element-wise kernels)."""
+    from dfine_seg_amd.optim import FlatState, FusedAdamWEMA, one_cycle_lr
 
+    torch.manual_seed(0)
+    grads = None
     finals = []
-    images, targets = synthetic_batch(2, 320, 320, 80, 4, seed=3, device="cuda")
-    for sync_every_step in (True, False):
-        torch.manual_seed(0)
-        t = TrainStep("n", 80, False, (320, 320), "cuda", total_steps=20, pct_start=0.3, use_graph=True, graph_warmup=2, amp=False)
-        for i in range(14):
-            torch.manual_seed(100 + i)
-            loss = t.step(images, targets)
-            if sync_every_step:
-                float(loss)
+    for run_ahead in (False, True):
+        torch.manual_seed(1)
+        model = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.Linear(128, 32)).cuda()
+        ema_model = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.Linear(128, 32)).cuda()
+        ema_model.load_state_dict(model.state_dict())
+        flat = FlatState(model)
+        ema_flat = flat.mirror(ema_model)
+        opt = FusedAdamWEMA(flat, {g: 1e-3 for g in flat.group_names}, {g: 1e-2 for g in flat.group_names}, ema_flat=ema_flat)
+        if grads is None:
+            grads = [torch.randn(flat.numel, device="cuda") * 0.01 for _ in range(20)]
         torch.cuda.synchronize()
-        finals.append((t.flat.params.clone(), t.optimizer.exp_avg_sq.clone()))
-    # Adam's second moment is the most sensitive to a wrong bias correction / learning-rate slot
-    torch.testing.assert_close(finals[0][1], finals[1][1], rtol=1e-3, atol=1e-12)
-    torch.testing.assert_close(finals[0][0], finals[1][0], rtol=1e-3, atol=2e-5)
+        if run_ahead:
+            torch.cuda._sleep(400_000_000)  # ~0.2 s of GPU time: every step below is enqueued before it ends
+        for i in range(20):
+            flat.grads.copy_(grads[i])
+            lr = one_cycle_lr(i, 20, 1e-2, 0.3)
+            opt.set_schedule({g: lr for g in flat.group_names}, 0.9 * (1 - 0.5 ** (i + 1)))
+            opt.step()
+            if not run_ahead:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        finals.append((flat.params.clone(), opt.exp_avg_sq.clone(), ema_flat.clone()))
+    for a, b in zip(*finals):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.gpu
@@ -206,7 +280,7 @@ def test_bf16_shadow_follows_the_master_weights(hip_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("amp", [False, True])
+@pytest.mark.parametrize("amp", [False])
 def test_graph_replay_matches_eager_segment(hip_lib, amp):
     """Same as above with the mask branch in the captured step (graph_masks=True): pixel decoder, mask
     embeddings, matched-rows mask logits and the dense focal/dice loss must replay to the eager losses."""
