@@ -32,6 +32,18 @@ class DFINE(nn.Module):
         return self.decoder(outs, inner, targets, inject)
 
 
+def _deploy(self):
+    """Inference form (reference DFINE.deploy, dfine.py:43-48): eval mode and every re-parameterisable block folded."""
+    self.eval()
+    for m in list(self.modules()):
+        if hasattr(m, "convert_to_deploy"):
+            m.convert_to_deploy()
+    return self
+
+
+DFINE.deploy = _deploy
+
+
 def load_checkpoint_state(model, path):
     """Accepts the layouts the reference's loader accepts (src/d_fine/utils.py:156-181):
     {"ema": {"module": sd}}, {"model": sd} or a bare state_dict; tensors only

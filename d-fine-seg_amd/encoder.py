@@ -18,7 +18,28 @@ class RepVgg(nn.Module):
         self.conv1 = ConvNorm(c, c, 3)
         self.conv2 = ConvNorm(c, c, 1)
 
+    def convert_to_deploy(self):
+        """3x3 + 1x1 branches and their norms folded into ONE 3x3 conv with bias (VGGBlock.convert_to_deploy,
+        hybrid_encoder.py:123-156)."""
+        if hasattr(self, "conv"):
+            return
+        from .layers import fuse_conv_norm
+
+        k3, b3 = fuse_conv_norm(self.conv1.conv, getattr(self.conv1, self.conv1.norm_name))
+        k1, b1 = fuse_conv_norm(self.conv2.conv, getattr(self.conv2, self.conv2.norm_name))
+        c = k3.shape[0]
+        conv = nn.Conv2d(c, c, 3, 1, padding=1).to(k3.device).to(memory_format=torch.channels_last)
+        conv.weight.data = (k3 + F.pad(k1, [1, 1, 1, 1])).contiguous(memory_format=torch.channels_last)
+        conv.bias.data = b3 + b1
+        self.conv = conv
+        delattr(self, "conv1")
+        delattr(self, "conv2")
+
     def forward(self, x):
+        if hasattr(self, "conv"):  # deployed
+            from . import ops
+
+            return ops.conv_bias_act(x, self.conv, "silu")
         return self.conv1(x, addend=self.conv2(x), act="silu")  # one fused norm+add+silu
 
 
@@ -108,6 +129,15 @@ class HybridEncoder(nn.Module):
         self.downsample_convs = nn.ModuleList(nn.Sequential(SCDown(hid, 3, 2)) for _ in range(L - 1))
         self.pan_blocks = nn.ModuleList(elan() for _ in range(L - 1))
         self._pos_cache = {}
+        # the layers the reference builds as ConvNormLayer_fuse (re-parameterised by deploy()): everything in the FPN / PAN
+        # except the RepVgg branches (folded as a pair by RepVgg.convert_to_deploy); the input projections stay conv + norm
+        for group in (self.lateral_convs, self.fpn_blocks, self.downsample_convs, self.pan_blocks):
+            for m in group.modules():
+                if isinstance(m, ConvNorm):
+                    m.deploy_fusable = True
+        for m in self.modules():
+            if isinstance(m, RepVgg):
+                m.conv1.deploy_fusable = m.conv2.deploy_fusable = False
 
     def _pos(self, w, h, device):
         key = (w, h, str(device))

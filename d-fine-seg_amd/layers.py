@@ -68,9 +68,29 @@ class ConvNorm(nn.Module):
         self._pending_batches = 0
         self.register_state_dict_pre_hook(ConvNorm._flush_batch_counter)
 
+    deploy_fusable = False  # set by the encoder on the layers the reference builds as ConvNormLayer_fuse
+
+    def convert_to_deploy(self):
+        """Inference re-parameterisation (reference ConvNormLayer_fuse.convert_to_deploy, hybrid_encoder.py:47-79): fold
+        the norm's running statistics and affine into the conv, which gains a bias; ``conv`` and the norm are removed."""
+        if not self.deploy_fusable or hasattr(self, "conv_bn_fused"):
+            return
+        kernel, bias = fuse_conv_norm(self.conv, getattr(self, self.norm_name))
+        c = self.conv
+        fused = nn.Conv2d(c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding, groups=c.groups, bias=True)
+        fused = fused.to(kernel.device).to(memory_format=torch.channels_last)
+        fused.weight.data = kernel.contiguous(memory_format=torch.channels_last)
+        fused.bias.data = bias
+        self.conv_bn_fused = fused
+        delattr(self, "conv")
+        delattr(self, self.norm_name)
+
     def forward(self, x, addend=None, act=None):
         """``addend`` (same shape as the output) is added after the norm, before the activation;
         ``act`` overrides the constructor's activation name (used by RepVgg: silu(a + b))."""
+        if hasattr(self, "conv_bn_fused"):  # deployed: conv + bias (+ activation)
+            y = ops.conv_bias_act(x, self.conv_bn_fused, act if act is not None else self.act_name, addend)
+            return self.lab(y) if hasattr(self, "lab") else y
         conv = self.conv
         norm = getattr(self, self.norm_name)
         frozen = isinstance(norm, FrozenBatchNorm2d)
@@ -113,10 +133,17 @@ class ConvNorm(nn.Module):
     def _flush_batch_counter(self, *args):
         # nn.BatchNorm2d counts forward calls in ``num_batches_tracked``; the fused path counts on the
         # host and writes the buffer only when a state_dict is taken (no per-layer launch per step)
-        norm = getattr(self, self.norm_name)
+        norm = getattr(self, self.norm_name, None)  # None once deployed (norm folded into the conv)
         if self._pending_batches and getattr(norm, "num_batches_tracked", None) is not None:
             norm.num_batches_tracked += self._pending_batches
         self._pending_batches = 0
+
+
+def fuse_conv_norm(conv, norm):
+    """(kernel, bias) of the conv equivalent to ``norm(conv(x))`` in eval mode (hybrid_encoder.py:68-79)."""
+    std = (norm.running_var + norm.eps).sqrt()
+    t = (norm.weight / std).reshape(-1, 1, 1, 1)
+    return (conv.weight * t).detach(), (norm.bias - norm.running_mean * norm.weight / std).detach()
 
 
 class LayerNorm(nn.LayerNorm):

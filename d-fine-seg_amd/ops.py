@@ -912,6 +912,35 @@ def dense_conv(x, weight, stride=1, padding=0, pad_br=None, stats=None, out=None
     return _DenseConv.apply(x, weight, int(stride), int(padding), pad_br, stats, out)
 
 
+def conv_bias_act(x, conv, act=None, addend=None):
+    """``act(conv(x) + bias + addend)`` for a deployed (norm-folded) nn.Conv2d, inference only: in bf16 mode on the GPU the
+    dense conv runs on the implicit-GEMM kernel with the bias (and ReLU) in its epilogue, a depthwise conv on the depthwise
+    kernel; otherwise the stock op."""
+    bf16_mode = x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16) and not torch.is_grad_enabled()
+    dense = conv.groups == 1 and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1] and conv.dilation == (1, 1)
+    depthwise = conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1
+    if bf16_mode and dense:
+        from . import gemm
+
+        fuse_relu = act == "relu" and addend is None
+        yl = gemm.conv_forward(gemm.nhwc(x.to(torch.bfloat16)), _khwc(conv.weight.detach().to(torch.bfloat16)), conv.stride[0],
+                               conv.padding[0], bias=conv.bias.detach().float(), relu=fuse_relu)
+        y = yl.permute(0, 3, 1, 2)
+        if fuse_relu:
+            return y
+    elif bf16_mode and depthwise:
+        y = depthwise_conv2d(x.to(torch.bfloat16), conv.weight, conv.stride[0]) + conv.bias.detach().to(torch.bfloat16).view(1, -1, 1, 1)
+    else:
+        y = conv(x)
+    if addend is not None:
+        y = y + addend
+    if act == "relu":
+        return torch.relu(y)
+    if act == "silu":
+        return torch.nn.functional.silu(y)
+    return y
+
+
 class _SelfAttention(torch.autograd.Function):
     """softmax(scale * Q K^T + mask) V on the projections' own layout; see include/dfine_hip.h (dfine_attention_*)."""
 
