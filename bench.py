@@ -40,7 +40,10 @@ def parse():
     ap.add_argument("--no-miopen-find", action="store_true",
                     help="leave torch.backends.cudnn.benchmark off (MIOpen then picks conv solvers by heuristic: ~13 %% slower steps, ~2 min less warm-up)")
     ap.add_argument("--bucketed-reducer", action="store_true",
-                    help="N>1: eager step + bucketed all-reduce overlapped with backward (default: captured graphs + one flat all-reduce)")
+                    help="N>1: eager step + bucketed all-reduce from autograd hooks (default: captured graphs, backward in three stages "
+                         "whose gradient ranges are all-reduced on a side stream while the next stage replays)")
+    ap.add_argument("--flat-reducer", action="store_true",
+                    help="N>1: captured graphs with ONE flat all-reduce between backward and optimizer (no overlap)")
     ap.add_argument("--force-ddp", action="store_true",
                     help="diagnostic: take the N>1 code path (process group, reducer, split graphs) even with one rank")
     ap.add_argument("--no-graph-masks", action="store_true", help="segment task: run mask batches eagerly (default: captured like detect)")
@@ -144,9 +147,11 @@ def main():
     if world > 1 or args.force_ddp:
         from dfine_seg_amd import ddp
 
-        # default: hipGraph(forward+backward) -> one flat RCCL all-reduce -> hipGraph(optimizer);
-        # --bucketed-reducer: eager step with bucket all-reduces overlapping backward on a side stream
-        reducer = ddp.BucketedGradReducer if args.bucketed_reducer else ddp.FlatGradAllReduce
+        # default: hipGraphs with backward cut into decoder / encoder / backbone stages, each stage's gradient ranges
+        # all-reduced over RCCL on a side stream while the next stage's graph replays (ddp.StagedGradAllReduce);
+        # --flat-reducer: one flat all-reduce after backward; --bucketed-reducer: eager step with autograd-hook buckets
+        reducer = (ddp.BucketedGradReducer if args.bucketed_reducer else
+                   ddp.FlatGradAllReduce if args.flat_reducer else ddp.StagedGradAllReduce)
     # the library convolutions (dense conv forward / input gradient): let MIOpen time its solvers once per
     # shape during the warm-up steps instead of trusting its heuristic (which favours split-K kernels that
     # need a zeroed fp32 workspace and a cast launch around them)

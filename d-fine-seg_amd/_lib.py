@@ -42,6 +42,7 @@ SIGNATURES = {
     "dfine_grad_sumsq": [_c_void_p, ctypes.c_longlong, _c_void_p, _c_void_p],
     "dfine_adamw_ema_step": [_c_void_p] * 8 + [ctypes.POINTER(ctypes.c_longlong), _c_int, ctypes.c_longlong, _c_void_p],
     "dfine_igemm_bf16": [_c_void_p] * 7,
+    "dfine_mask_targets_nearest": [_c_void_p, _c_void_p, ctypes.c_longlong] + [_c_int] * 4 + [_c_void_p],
     "dfine_postprocess_topk": [_c_void_p, _c_int] + [_c_void_p] * 6 + [_c_int] * 7 + [_c_void_p],
     "dfine_postprocess_masks": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_int] * 8 + [ctypes.c_float, _c_void_p],
     "dfine_attention_fwd": [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p, _c_void_p, _c_int, _c_void_p] + [_c_int] * 4 + [ctypes.c_float, _c_void_p],

@@ -19,6 +19,24 @@ __device__ __forceinline__ float round_to<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 
+// E consecutive elements per lane; E = 6 (D = 384, the x-size AIFI layer) is not a power-of-two vector: three 2-element pieces
+template <typename T, int E>
+__device__ __forceinline__ void lv(const T* p, float* f) {
+  if constexpr (E == 6) {
+    load_vec<T, 2>(p, f), load_vec<T, 2>(p + 2, f + 2), load_vec<T, 2>(p + 4, f + 4);
+  } else {
+    load_vec<T, E>(p, f);
+  }
+}
+template <typename T, int E>
+__device__ __forceinline__ void sv(T* p, const float* f) {
+  if constexpr (E == 6) {
+    store_vec<T, 2>(p, f), store_vec<T, 2>(p + 2, f + 2), store_vec<T, 2>(p + 4, f + 4);
+  } else {
+    store_vec<T, E>(p, f);
+  }
+}
+
 template <typename T, int E>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -32,10 +50,10 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
   for (int i = 0; i < E; ++i) g[i] = gamma[lane * E + i], b[i] = beta[lane * E + i];
   for (long long row = wave; row < M; row += n_waves) {
     float v[E];
-    load_vec<T, E>(x + row * D + lane * E, v);
+    lv<T, E>(x + row * D + lane * E, v);
     if (res) {
       float r[E];
-      load_vec<T, E>(res + row * D + lane * E, r);
+      lv<T, E>(res + row * D + lane * E, r);
 #pragma unroll
       for (int i = 0; i < E; ++i) v[i] += r[i];
     }
@@ -44,7 +62,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
       for (int i = 0; i < E; ++i) v[i] = fminf(fmaxf(v[i], -clamp), clamp);
     }
     if (s_out) {  // the normalised quantity as the backward will read it (rounded to T)
-      store_vec<T, E>(s_out + row * D + lane * E, v);
+      sv<T, E>(s_out + row * D + lane * E, v);
 #pragma unroll
       for (int i = 0; i < E; ++i) v[i] = round_to<T>(v[i]);
     }
@@ -59,7 +77,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
     float o[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) o[i] = (v[i] - mean) * rstd * g[i] + b[i];
-    store_vec<T, E>(y + row * D + lane * E, o);
+    sv<T, E>(y + row * D + lane * E, o);
     if (lane == 0) mean_out[row] = mean, rstd_out[row] = rstd;
   }
 }
@@ -79,8 +97,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
   for (int i = 0; i < E; ++i) g[i] = gamma[lane * E + i], ag[i] = 0.f, ab[i] = 0.f;
   for (long long row = wave; row < M; row += n_waves) {
     float d[E], v[E];
-    load_vec<T, E>(dy + row * D + lane * E, d);
-    load_vec<T, E>(s + row * D + lane * E, v);
+    lv<T, E>(dy + row * D + lane * E, d);
+    lv<T, E>(s + row * D + lane * E, v);
     const float mean = mean_in[row], rstd = rstd_in[row];
     float c1 = 0.f, c2 = 0.f, xh[E];
 #pragma unroll
@@ -100,7 +118,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
       o[i] = rstd * (d[i] * g[i] - c1 - xh[i] * c2);
       if (clamp > 0.f && (v[i] <= -clamp || v[i] >= clamp)) o[i] = 0.f;  // clamp's gradient (saturated: 0)
     }
-    store_vec<T, E>(ds + row * D + lane * E, o);
+    sv<T, E>(ds + row * D + lane * E, o);
   }
 #pragma unroll
   for (int i = 0; i < E; ++i) red[0][w][lane * E + i] = ag[i], red[1][w][lane * E + i] = ab[i];
@@ -134,10 +152,12 @@ static int launch_ln(bool fwd, const void* a, const void* b, const float* gamma,
     if (dtype == DFINE_DT_BF16) {                               \
       if (D == 128) return CALL(bf16_t, 2);                     \
       if (D == 256) return CALL(bf16_t, 4);                     \
+      if (D == 384) return CALL(bf16_t, 6);                     \
       if (D == 512) return CALL(bf16_t, 8);                     \
     } else if (dtype == DFINE_DT_F32) {                         \
       if (D == 128) return CALL(float, 2);                      \
       if (D == 256) return CALL(float, 4);                      \
+      if (D == 384) return CALL(float, 6);                      \
     }                                                           \
     return DFINE_E_UNSUPPORTED;                                 \
   } while (0)

@@ -49,9 +49,38 @@ __global__ __launch_bounds__(256) void embedding_wgrad_kernel(const long long* _
   }
 }
 
+// GT masks -> loss targets: F.interpolate(mask.float(), size=(Hm, Wm), mode="nearest").clamp(0, 1) for every (image, slot)
+// of a packed uint8 batch (reference dfine_criterion.py:239-270). PyTorch's nearest source index: min(floor(dst * scale), in-1)
+// with scale = float(in) / float(out).
+__global__ __launch_bounds__(256) void mask_targets_nearest_kernel(const unsigned char* __restrict__ masks, float* __restrict__ out,
+                                                                  long long n_maps, int H, int W, int Hm, int Wm) {
+  const float sy = (float)H / (float)Hm, sx = (float)W / (float)Wm;
+  const long long total = n_maps * Hm * Wm;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wm);
+    const long long t = i / Wm;
+    const int y = (int)(t % Hm);
+    const long long m = t / Hm;
+    const int iy = min((int)floorf((float)y * sy), H - 1), ix = min((int)floorf((float)x * sx), W - 1);
+    out[i] = masks[(m * H + iy) * W + ix] ? 1.f : 0.f;
+  }
+}
+
 }  // namespace dfine
 
 using namespace dfine;
+
+extern "C" int dfine_mask_targets_nearest(const unsigned char* masks, float* out, long long n_maps, int H, int W, int Hm, int Wm,
+                                          void* stream) {
+  if (!masks || !out) return DFINE_E_BADARG;
+  if (n_maps <= 0 || H <= 0 || W <= 0 || Hm <= 0 || Wm <= 0) return DFINE_E_BADARG;
+  long long blocks = (n_maps * Hm * Wm + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(mask_targets_nearest_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, masks, out, n_maps, H, W, Hm,
+                     Wm);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int dfine_transpose_weights(const void* src, void* dst, const long long* table, const int* blocks,
                                        int n_blocks, void* stream) {

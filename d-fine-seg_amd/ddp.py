@@ -192,3 +192,72 @@ class FlatGradAllReduce:
 
     def zero_grad(self):
         self.flat.grads.zero_()
+
+
+class StagedGradAllReduce(FlatGradAllReduce):
+    """The north-star schedule WITH graphs: backward is captured as three hipGraphs cut at the module boundaries
+    (criterion + decoder | encoder | backbone); as soon as a stage's graph has been enqueued, the contiguous ranges of the
+    flat gradient buffer that stage filled are all-reduced (mean) on a SIDE stream, while the next stage's graph replays
+    on the main stream -- the collectives never sit inside a capture and only the last stage's message (the backbone's
+    gradients, ~1/3 of the bytes) is exposed. ``TrainStep`` drives it (``staged = True``):
+
+        graph(forward + matching) -> 2-float all-reduce -> graph(loss + decoder bwd) -> [side: all-reduce decoder ranges]
+        -> graph(encoder bwd) -> [side: encoder ranges] -> graph(backbone bwd) -> [side: backbone ranges] -> join -> graph(optimizer)
+
+    The flat layout makes this possible: inside each optimizer group the parameters are ordered by module in reverse
+    registration order, so every (module, group) pair is ONE contiguous range (reference: DDP's reducer overlaps 25 MB
+    buckets with an eagerly launched backward, src/dl/train.py:157-169)."""
+
+    graph_safe = True
+    staged = True
+    stage_prefixes = ("decoder.", "encoder.", "backbone.")
+
+    def __init__(self, model, process_group=None, broadcast_parameters=True, stage_prefixes=None):
+        super().__init__(model, num_chunks=1, process_group=process_group, broadcast_parameters=broadcast_parameters)
+        if stage_prefixes is not None:
+            self.stage_prefixes = tuple(stage_prefixes)
+        self.on_gpu = self.flat.device.type == "cuda"
+        self.side_stream = torch.cuda.Stream(self.flat.device) if self.on_gpu else None
+        self.stage_ranges = []
+        for prefix in self.stage_prefixes:
+            runs = []
+            for name, p, off, n, _ in sorted((e for e in self.flat.entries if e[0].startswith(prefix)), key=lambda e: e[2]):
+                if runs and off - runs[-1][1] < 64:  # alignment padding between neighbours: keep one run
+                    runs[-1][1] = off + n
+                else:
+                    runs.append([off, off + n])
+            self.stage_ranges.append([self.flat.grads[a:b] for a, b in runs])
+        covered = sum(t.numel() for rs in self.stage_ranges for t in rs)
+        owned = sum(e[3] for e in self.flat.entries)
+        if covered < owned:
+            raise RuntimeError("StagedGradAllReduce: a trainable parameter belongs to none of decoder / encoder / backbone")
+
+    def reduce_stage(self, stage):
+        """All-reduce the gradient ranges of ``stage`` on the side stream, after the work enqueued so far on the
+        current stream (the stage's backward graph)."""
+        if self.on_gpu:
+            self.side_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side_stream):
+                self._reduce_ranges(self.stage_ranges[stage])
+        else:
+            self._reduce_ranges(self.stage_ranges[stage])
+
+    def _reduce_ranges(self, ranges):
+        for r in ranges:
+            if self.backend_has_avg:
+                dist.all_reduce(r, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(r, op=dist.ReduceOp.SUM, group=self.group)
+                r.div_(self.world)
+
+    def join(self):
+        """The optimizer (current stream) waits for every stage's collective."""
+        if self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
+
+    def reduce(self):  # eager path (warm-up steps): everything at once, on the side stream, then join
+        for stage in range(len(self.stage_ranges)):
+            self.reduce_stage(stage)
+        self.join()
+
+    finish = reduce

@@ -608,7 +608,7 @@ class _AddLayerNorm(torch.autograd.Function):
 
 
 def add_layer_norm_supported(x, dim):
-    return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and (dim in (128, 256) or (dim == 512 and x.dtype == torch.bfloat16))
+    return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and (dim in (128, 256, 384) or (dim == 512 and x.dtype == torch.bfloat16))
 
 
 def add_layer_norm(x, res, weight, bias, eps=1e-5, clamp=None):
@@ -806,7 +806,7 @@ def linear(x, weight, bias=None, row_begin=0, row_end=None, relu=False):
     row_end = weight.shape[0] if row_end is None else row_end
     n, k = row_end - row_begin, weight.shape[1]
     bf16_mode = x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16)
-    if not bf16_mode or n % 2 or k % 2:
+    if not bf16_mode:
         w = weight if (row_begin == 0 and row_end == weight.shape[0]) else weight[row_begin:row_end]
         b = bias if (bias is None or (row_begin == 0 and row_end == weight.shape[0])) else bias[row_begin:row_end]
         y = torch.nn.functional.linear(x, w, b)

@@ -67,9 +67,14 @@ class TargetBatch:
 
     def dense_mask_targets(self, out_h, out_w, device):
         """[B, G, out_h, out_w] fp32 targets, computed once per batch (``mask_tgt``); a captured step is
-        handed the tensor ready-made (train.TrainStep) so the per-image resize stays outside the graph."""
+        handed the tensor ready-made (train.TrainStep) so the staging stays outside the graph. On the GPU the uint8
+        masks of the whole batch cross PCIe once through a pinned double buffer and are resized by one kernel
+        (``MaskStager``); ``mask_targets`` below is the per-image formulation it is tested against."""
         if self.mask_tgt is None or tuple(self.mask_tgt.shape[-2:]) != (out_h, out_w):
-            self.mask_tgt = self.mask_targets(out_h, out_w, device)[0]
+            staged = None
+            if torch.device(device).type == "cuda":
+                staged = MaskStager.for_device(device).stage(self.masks, self.labels.shape[1], out_h, out_w)
+            self.mask_tgt = staged if staged is not None else self.mask_targets(out_h, out_w, device)[0]
         return self.mask_tgt
 
     def mask_targets(self, out_h, out_w, device):
@@ -86,3 +91,58 @@ class TargetBatch:
             out[i, : m.shape[0]] = F.interpolate(m[None].float(), size=(out_h, out_w), mode="nearest")[0].clamp_(0, 1)
             has[i] = True
         return out, has.to(device)
+
+
+class MaskStager:
+    """Input staging of the ground-truth masks: the per-image uint8 masks [n_i, H, W] of a batch are
+    packed into ONE pinned host buffer [B, G, H, W] (two buffers, alternating, each guarded by an event so the host never
+    overwrites a buffer whose copy is still in flight), copied to the device in one async transfer and turned into the
+    loss targets [B, G, Hm, Wm] fp32 by one HIP kernel (dfine_mask_targets_nearest, bit-exact with the reference's
+    F.interpolate(nearest)). The reference moves every image's masks with its own ``.to(device)`` inside the criterion."""
+
+    _instances = {}
+
+    @classmethod
+    def for_device(cls, device):
+        key = str(torch.device(device))
+        if key not in cls._instances:
+            cls._instances[key] = cls(device)
+        return cls._instances[key]
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.host, self.dev, self.events, self.turn = [None, None], [None, None], [None, None], 0
+
+    def stage(self, masks, G, out_h, out_w):
+        """masks: list (per image) of uint8 [n_i, H, W] CPU tensors or None -> fp32 [B, G, out_h, out_w] on the device, or
+        None when the masks are not host uint8 maps of one size (the caller then takes the generic path)."""
+        from . import _lib
+
+        shapes = {tuple(m.shape[-2:]) for m in masks if m is not None and m.numel() > 0}
+        if len(shapes) != 1 or any(m is not None and (m.is_cuda or m.dtype != torch.uint8 or m.dim() != 3) for m in masks):
+            return None
+        (H, W), B = shapes.pop(), len(masks)
+        slot = self.turn
+        self.turn ^= 1
+        n = B * G * H * W
+        if self.host[slot] is None or self.host[slot].numel() < n:
+            self.host[slot] = torch.zeros(n, dtype=torch.uint8).pin_memory()
+            self.dev[slot] = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()  # the transfer that last read this pinned buffer has finished
+        host = self.host[slot][:n].view(B, G, H, W)
+        for i, m in enumerate(masks):
+            k = 0 if m is None else min(int(m.shape[0]), G)
+            if k:
+                host[i, :k].copy_(m[:k])
+            host[i, k:].zero_()
+        dev = self.dev[slot][:n]
+        dev.copy_(self.host[slot][:n], non_blocking=True)
+        ev = self.events[slot] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.events[slot] = ev
+        out = torch.empty(B, G, out_h, out_w, dtype=torch.float32, device=self.device)
+        lib = _lib.load()
+        rc = lib.dfine_mask_targets_nearest(_lib.ptr(dev), _lib.ptr(out), B * G, H, W, out_h, out_w, _lib.stream_ptr())
+        _lib.check(rc, "dfine_mask_targets_nearest")
+        return out

@@ -76,6 +76,22 @@ class _SplitGraph:
         self.tail.replay()
 
 
+class _StagedGraph:
+    """Data-parallel step with the gradient exchange overlapped: see ddp.StagedGradAllReduce."""
+
+    def __init__(self, head, reduce_norm, stages, reducer, tail):
+        self.head, self.reduce_norm, self.stages, self.reducer, self.tail = head, reduce_norm, stages, reducer, tail
+
+    def replay(self):
+        self.head.replay()
+        self.reduce_norm()
+        for i, g in enumerate(self.stages):
+            g.replay()
+            self.reducer.reduce_stage(i)  # side stream: overlaps the next stage's replay
+        self.reducer.join()
+        self.tail.replay()
+
+
 class TrainStep:
     """model + criterion + fused optimizer + OneCycle schedule + EMA; ``step(images, targets)`` runs
     one iteration and returns the (device-resident) total loss."""
@@ -142,16 +158,37 @@ class TrainStep:
                 b.copy_(live_b[n])
 
     # ------------------------------------------------------------------ one step, device side
-    def _forward_match(self, images, tb, inject=None):
-        """Model forward and the matchings; returns (outputs, criterion state) -- no collective inside."""
+    def _forward_match(self, images, tb, inject=None, cuts=None):
+        """Model forward and the matchings; returns (outputs, criterion state) -- no collective inside. ``cuts`` (a dict):
+        run the three modules with the autograd graph CUT at their boundaries (detached leaves), recording what
+        ``_staged_backward`` needs to chain the pieces -- same arithmetic, backward in three separately capturable parts."""
         from . import ops
 
         ops.zero_arena = self.arena  # this step's scratch (module-level handle: the ops are free functions)
         if self.arena is not None:
             self.arena.reset()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
-            out = self.model(images, targets=tb, inject=inject)
+            if cuts is None:
+                out = self.model(images, targets=tb, inject=inject)
+            else:
+                m = self.model
+                feats = m.backbone(images.contiguous(memory_format=torch.channels_last))
+                feats_cut = [f.detach().requires_grad_(True) for f in feats]
+                outs, inner = m.encoder(feats_cut)
+                leaf = {}
+                for t in list(outs) + list(inner):  # inner[0] IS outs[0]: one leaf per distinct tensor
+                    if id(t) not in leaf:
+                        leaf[id(t)] = (t, t.detach().requires_grad_(True))
+                out = m.decoder([leaf[id(t)][1] for t in outs], [leaf[id(t)][1] for t in inner], tb, inject)
+                cuts.update(feats=feats, feats_cut=feats_cut, enc=list(leaf.values()))
         return out, self.criterion.match(out)  # fp32, outside autocast like train.py:548-549
+
+    @staticmethod
+    def _backward_through(pairs):
+        """Continue backward from cut leaves into the graph that produced them: pairs of (producer output, leaf)."""
+        live = [(t, l.grad) for t, l in pairs if l.grad is not None and t.requires_grad]
+        if live:
+            torch.autograd.backward([t for t, _ in live], [g for _, g in live])
 
     def _loss_backward(self, out, state):
         losses = self.criterion.compute_losses(out, state)
@@ -266,17 +303,31 @@ class TrainStep:
             if self._graph_pool is None:
                 self._graph_pool = graph.pool()
             return graph, s_images, s_tb, s_loss, s_leaves
-        # data parallel: three graphs; the two collectives (2-float normaliser all-reduce of the criterion,
-        # gradient all-reduce) run between their replays and are never part of a capture
+        # data parallel: several graphs; the collectives (2-float normaliser all-reduce of the criterion, gradient
+        # all-reduces) run between their replays and are never part of a capture
+        staged = getattr(self.grad_reducer, "staged", False)
+        cuts = {} if staged else None
         with torch.cuda.graph(graph, **pool_kw):
-            out, state = self._forward_match(s_images, s_tb, s_inject)
+            out, state = self._forward_match(s_images, s_tb, s_inject, cuts)
         if self._graph_pool is None:
             self._graph_pool = graph.pool()
+        reduce_norm = lambda: self.criterion.reduce_normalisers(state)
+        if staged:  # backward in three graphs cut at the module boundaries; each stage's gradients leave on the side stream
+            stages = [torch.cuda.CUDAGraph() for _ in range(3)]
+            with torch.cuda.graph(stages[0], pool=graph.pool()):
+                s_loss = self._loss_backward(out, state)  # criterion + decoder; fills the cut leaves' .grad
+            with torch.cuda.graph(stages[1], pool=graph.pool()):
+                self._backward_through(cuts["enc"])  # encoder
+            with torch.cuda.graph(stages[2], pool=graph.pool()):
+                self._backward_through(list(zip(cuts["feats"], cuts["feats_cut"])))  # backbone
+            tail = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(tail, pool=graph.pool()):
+                self._optimizer_tail()
+            return _StagedGraph(graph, reduce_norm, stages, self.grad_reducer, tail), s_images, s_tb, s_loss, s_leaves
         middle = torch.cuda.CUDAGraph()
         with torch.cuda.graph(middle, pool=graph.pool()):
             s_loss = self._loss_backward(out, state)
         tail = torch.cuda.CUDAGraph()
         with torch.cuda.graph(tail, pool=graph.pool()):
             self._optimizer_tail()
-        reduce_norm = lambda: self.criterion.reduce_normalisers(state)
         return _SplitGraph(graph, reduce_norm, middle, self.grad_reducer, tail), s_images, s_tb, s_loss, s_leaves

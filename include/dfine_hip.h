@@ -300,7 +300,7 @@ int dfine_mask_loss_grad(const void* logits, int dtype, const float* tgt, const 
  *   res is NULL and clamp <= 0) to the backward as `s`; the statistics are taken on the rounded s.
  * Backward: ds = d(loss)/d(s) (= gradient of both x and res; 0 where the clamp saturated);
  *   dgamma / dbeta are ACCUMULATED with float atomics.
- * D in {128, 256, 512} (512: bf16 only).
+ * D in {128, 256, 384, 512} (512: bf16 only).
  * ------------------------------------------------------------------------------------- */
 int dfine_add_layernorm_fwd(const void* x, const void* res, int dtype, const float* gamma, const float* beta, void* y,
                             void* s_out, float* mean, float* rstd, long long M, int D, float eps, float clamp,
@@ -412,6 +412,16 @@ int dfine_postprocess_topk(const void* logits, int dtype, const float* boxes, co
 int dfine_postprocess_masks(const void* probs, int dtype, const long long* qidx, const float* boxes, unsigned char* out,
                             int n_inst, int Hm, int Wm, int proc_h, int proc_w, int H0, int W0, int keep_ratio, float thresh,
                             void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Mask-loss targets from a packed batch of ground-truth masks (input staging, reference
+ * src/d_fine/dfine_criterion.py:239-270 _prepare_target_masks: per image m.float() -> F.interpolate(size=(Hm, Wm),
+ * mode="nearest") -> clamp(0, 1)): masks u8 [n_maps, H, W] (n_maps = B*G padded slots, zero maps for padding)
+ * -> out f32 [n_maps, Hm, Wm] in {0, 1}; source pixel = min(floor(dst * float(in)/float(out)), in - 1), bit-exact
+ * with PyTorch's nearest rule.
+ * ------------------------------------------------------------------------------------- */
+int dfine_mask_targets_nearest(const unsigned char* masks, float* out, long long n_maps, int H, int W, int Hm, int Wm,
+                               void* stream);
 
 #ifdef __cplusplus
 }

@@ -119,6 +119,48 @@ def test_flat_allreduce_world2_gloo():
         assert dict(result) == {0: "ok", 1: "ok"}
 
 
+def _staged_worker(rank, world, port, result):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dfine_seg_amd.ddp import StagedGradAllReduce
+
+        torch.manual_seed(100 + rank)
+        model = Toy()
+        reducer = StagedGradAllReduce(model, stage_prefixes=("c.", "b.", "a.", "unused."))  # backward order of the toy
+        assert [len(r) for r in reducer.stage_ranges] == [1, 1, 1, 1]
+        # every trainable element lies in exactly one stage range (ranges also span the zero alignment padding between tensors)
+        assert sum(t.numel() for rs in reducer.stage_ranges for t in rs) >= sum(p.numel() for p in model.parameters() if p.requires_grad)
+        for step in range(2):
+            x = torch.randn(5, 8, generator=torch.Generator().manual_seed(step * 10 + rank))
+            model(x).pow(2).sum().backward()
+            expect = {}
+            for n, p in model.named_parameters():
+                if p.requires_grad:
+                    t = p.grad.clone()
+                    dist.all_reduce(t)
+                    expect[n] = t / world
+            for stage in range(4):  # stage by stage, as TrainStep drives it between its backward graphs
+                reducer.reduce_stage(stage)
+                done = reducer.stage_prefixes[: stage + 1]
+                for n, p in model.named_parameters():
+                    if p.requires_grad and n.startswith(done):
+                        torch.testing.assert_close(p.grad, expect[n], rtol=1e-6, atol=1e-7)
+            reducer.join()
+            reducer.zero_grad()
+        result[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_staged_allreduce_world2_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        result = mgr.dict()
+        mp.spawn(_staged_worker, args=(world, _free_port(), result), nprocs=world, join=True)
+        assert dict(result) == {0: "ok", 1: "ok"}
+
+
 def _shadow_worker(rank, world, port, result):
     """Ranks start from DIFFERENT weights with the bf16 shadow already built (TrainStep's order of construction): after
     either reducer's broadcast the shadow the compute path reads must be bf16(rank 0's weights) on every rank."""
@@ -278,14 +320,14 @@ _RCCL_GRAPH_SCRIPT = """
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, {root!r})
 import dfine_seg_amd
-from dfine_seg_amd.ddp import FlatGradAllReduce
+from dfine_seg_amd.ddp import FlatGradAllReduce, StagedGradAllReduce
 from dfine_seg_amd.synth import synthetic_batch
-from dfine_seg_amd.train import TrainStep, _SplitGraph
+from dfine_seg_amd.train import TrainStep, _SplitGraph, _StagedGraph
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT={port!r}, RANK="0", WORLD_SIZE="1")
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 images, targets = synthetic_batch(2, 320, 320, 80, 4, seed=1, device="cuda")
 losses = []
-for reducer in (None, FlatGradAllReduce):
+for reducer in (None, FlatGradAllReduce, StagedGradAllReduce):
     torch.manual_seed(0)
     trainer = TrainStep("n", 80, False, (320, 320), "cuda", grad_reducer=reducer, total_steps=100, graph_warmup=2, amp=False)
     out = []
@@ -294,10 +336,14 @@ for reducer in (None, FlatGradAllReduce):
         out.append(float(trainer.step(images, targets)))
     losses.append(out)
     assert len(trainer._graphs) == 1
-    assert isinstance(next(iter(trainer._graphs.values()))[0], _SplitGraph) == (reducer is not None)
+    kind = {{None: torch.cuda.CUDAGraph, FlatGradAllReduce: _SplitGraph, StagedGradAllReduce: _StagedGraph}}[reducer]
+    assert isinstance(next(iter(trainer._graphs.values()))[0], kind)
     assert float(trainer.flat.grads.abs().max()) == 0.0
-for a, b in zip(*losses):
-    assert abs(a - b) <= 5e-3 * abs(a), losses  # fp32 steps; float-atomic order is the only run-to-run difference
+for other in losses[1:]:
+    for i, (a, b) in enumerate(zip(losses[0], other)):
+        # fp32 steps; float-atomic order is the only run-to-run difference, but it is amplified step over step (a Hungarian
+        # assignment can flip on a round-off): tight on the first steps, loose on the last
+        assert abs(a - b) <= (2e-3 if i < 3 else 2e-2) * abs(a), losses
 dist.destroy_process_group()
 print("RCCL_GRAPH_OK")
 """
@@ -305,8 +351,10 @@ print("RCCL_GRAPH_OK")
 
 @pytest.mark.gpu
 def test_flat_allreduce_between_captured_graphs_rccl_single_rank(hip_lib):
-    """bench.py's N>1 schedule on the one GPU of the test box (1-rank RCCL group): graph(forward+backward)
-    -> flat all-reduce -> graph(optimizer) must follow the same loss trajectory as the single-GPU graph."""
+    """bench.py's N>1 schedules on the one GPU of the test box (1-rank RCCL group): the flat schedule (graph(forward+backward)
+    -> flat all-reduce -> graph(optimizer)) and the default staged schedule (backward cut into decoder / encoder / backbone
+    graphs, each stage's gradient ranges all-reduced on a side stream under the next stage) must follow the same loss
+    trajectory as the single-GPU graph."""
     import subprocess
     import sys
 

@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,D,with_res,clamp", [(15744, 256, True, None), (1000, 256, False, None), (77, 128, True, 3.0),
-                                                 (9600, 256, True, 65504.0), (5, 128, False, None), (300, 512, True, None)])
+                                                 (9600, 256, True, 65504.0), (5, 128, False, None), (300, 512, True, None),
+                                                 (1800, 384, True, None)])  # 384: D-FINE-x AIFI
 def test_add_layer_norm_matches_torch(hip_lib, dtype, M, D, with_res, clamp):
     from dfine_seg_amd import ops
 
@@ -56,6 +57,6 @@ def test_add_layer_norm_matches_torch(hip_lib, dtype, M, D, with_res, clamp):
 def test_add_layer_norm_unsupported_width(hip_lib):
     from dfine_seg_amd import _lib
 
-    z = torch.zeros(4 * 384, device="cuda")
+    z = torch.zeros(4 * 320, device="cuda")
     assert hip_lib.dfine_add_layernorm_fwd(_lib.ptr(z), None, 0, _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), None, _lib.ptr(z), _lib.ptr(z),
-                                           4, 384, 1e-5, 0.0, None) == -2
+                                           4, 320, 1e-5, 0.0, None) == -2

