@@ -118,6 +118,11 @@ def load_pmc_traffic():
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to stdout when the first communicator is
+    # created, so everything else this process writes to fd 1 is sent to stderr and the JSON goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -239,7 +244,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(trainer.model, args)
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -280,6 +280,21 @@ class TrainStep:
         return s_loss
 
     def _capture(self, images, tb, inject=None):
+        """See ``_capture_impl``. Python's cyclic GC is held off for the duration: a hipGraph object of an earlier TrainStep
+        (or any other tensor-owning cycle) finalised in the middle of a capture calls hipGraphDestroy / hipFree while the
+        stream is capturing -- "operation not permitted when stream is capturing", raised from a destructor = abort."""
+        import gc
+
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            return self._capture_impl(images, tb, inject)
+        finally:
+            if was_enabled:
+                gc.enable()
+
+    def _capture_impl(self, images, tb, inject=None):
         """Capture the step for this (batch shape, padded GT width, max GT count). The per-image GT
         counts inside may vary between replays; the maximum (it fixes the number of denoising
         queries) may not -- a new maximum gets its own graph."""
@@ -297,6 +312,13 @@ class TrainStep:
                     s_inject.setdefault(path[0], {})[path[1]] = t
         graph = torch.cuda.CUDAGraph()
         pool_kw = {"pool": self._graph_pool} if self._graph_pool is not None else {}
+        # With a process group alive, c10d's watchdog THREAD polls hipEventQuery on in-flight collectives; under the default
+        # "global" capture mode HIP forbids that call process-wide while any thread captures ("operation not permitted when
+        # stream is capturing"), the watchdog's exception is uncaught and the process aborts. Captures are therefore
+        # thread-local in data-parallel runs (kernels the autograd thread launches on the capturing stream are still captured).
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            pool_kw["capture_error_mode"] = "thread_local"
+            torch.cuda.synchronize()  # and no collective of the eager warm-up steps is still in flight
         if self.grad_reducer is None:
             with torch.cuda.graph(graph, **pool_kw):
                 s_loss = self._body(s_images, s_tb, s_inject)
@@ -314,20 +336,20 @@ class TrainStep:
         reduce_norm = lambda: self.criterion.reduce_normalisers(state)
         if staged:  # backward in three graphs cut at the module boundaries; each stage's gradients leave on the side stream
             stages = [torch.cuda.CUDAGraph() for _ in range(3)]
-            with torch.cuda.graph(stages[0], pool=graph.pool()):
+            with torch.cuda.graph(stages[0], **{**pool_kw, 'pool': graph.pool()}):
                 s_loss = self._loss_backward(out, state)  # criterion + decoder; fills the cut leaves' .grad
-            with torch.cuda.graph(stages[1], pool=graph.pool()):
+            with torch.cuda.graph(stages[1], **{**pool_kw, 'pool': graph.pool()}):
                 self._backward_through(cuts["enc"])  # encoder
-            with torch.cuda.graph(stages[2], pool=graph.pool()):
+            with torch.cuda.graph(stages[2], **{**pool_kw, 'pool': graph.pool()}):
                 self._backward_through(list(zip(cuts["feats"], cuts["feats_cut"])))  # backbone
             tail = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(tail, pool=graph.pool()):
+            with torch.cuda.graph(tail, **{**pool_kw, 'pool': graph.pool()}):
                 self._optimizer_tail()
             return _StagedGraph(graph, reduce_norm, stages, self.grad_reducer, tail), s_images, s_tb, s_loss, s_leaves
         middle = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(middle, pool=graph.pool()):
+        with torch.cuda.graph(middle, **{**pool_kw, 'pool': graph.pool()}):
             s_loss = self._loss_backward(out, state)
         tail = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(tail, pool=graph.pool()):
+        with torch.cuda.graph(tail, **{**pool_kw, 'pool': graph.pool()}):
             self._optimizer_tail()
         return _SplitGraph(graph, reduce_norm, middle, self.grad_reducer, tail), s_images, s_tb, s_loss, s_leaves
