@@ -29,6 +29,8 @@
 // row-contiguous stores. Global -> LDS staging is through registers (the gather zero-fills padding taps and
 // rows beyond M), one K step ahead, one barrier per K step. Tiles of one M range share an XCD (its L2 holds
 // the activation rows all N tiles re-read and the halo rows neighbouring M tiles share).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dfine {
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const bf16_t* __restrict_
   constexpr int A_CH = BM / RPP, B_CH = (BN + RPP - 1) / RPP;  // chunks per thread per K step
   constexpr int STAGE = (BM + BN) * BK;       // bf16 elements per LDS stage
   constexpr int CPITCH = BN + 8;              // epilogue tile row pitch (elements): 16 bytes of padding
-  constexpr int LDS_MAIN = 2 * STAGE * 2, LDS_EPI = BM * CPITCH * 2 + 2 * BN * 4 * 4;
+  constexpr int LDS_MAIN = 2 * STAGE * 2, LDS_EPI = BM * CPITCH * 2 + 2 * (256 / (BN / 8)) * BN * 4;  // C tile + statistics partials
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[(LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI) + 64];
   bf16_t* const lds = reinterpret_cast<bf16_t*>(lds_raw);
   int* const tap_tab = reinterpret_cast<int*>(lds_raw + (LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI));
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const bf16_t* __restrict_
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v[e] = acc[i][j][e] + bv[e];
-        if (g.act == 1) v[e] = fmaxf(v[e], 0.f);
+        if ((g.act & 0xff) == 1) v[e] = fmaxf(v[e], 0.f);
       }
       uint2 pk;
       pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
@@ -300,28 +302,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const bf16_t* __restrict_
       }
     }
   }
-  if (stats != nullptr) {
-    // threads with the same chunk column: lanes o_j + k*OCPR of every wave -> shuffle within the wave, LDS across waves
-    float* red = reinterpret_cast<float*>(lds_raw + BM * CPITCH * 2);  // [2][BN] after the C tile
-    if (tid < 2 * BN) red[tid] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float a = s1[e], b = s2[e];
-#pragma unroll
-      for (int d = OCPR; d < 64; d <<= 1) {
-        a += __shfl_xor(a, d, 64);
-        b += __shfl_xor(b, d, 64);
-      }
-      if (lane < OCPR) {
-        atomicAdd(red + o_j * 8 + e, a);
-        atomicAdd(red + BN + o_j * 8 + e, b);
-      }
-    }
+  if (stats != nullptr && (g.act & 0x200) == 0) {
+    // column sums over the tile's rows: every thread parks its 8 + 8 partial sums (its chunk column, its ORPP-strided
+    // rows) in LDS behind the C tile, then thread c (< BN) adds the ORPP partials of column c and thread BN + c those of
+    // its squares -- plain LDS traffic, no shuffles and no LDS atomics (that form cost 9 us on a 30 us launch)
+    float* part = reinterpret_cast<float*>(lds_raw + BM * CPITCH * 2);  // [2][ORPP][BN]
+    float4* p1 = reinterpret_cast<float4*>(part + (0 * ORPP + o_r) * BN + o_j * 8);
+    float4* p2 = reinterpret_cast<float4*>(part + (1 * ORPP + o_r) * BN + o_j * 8);
+    p1[0] = make_float4(s1[0], s1[1], s1[2], s1[3]), p1[1] = make_float4(s1[4], s1[5], s1[6], s1[7]);
+    p2[0] = make_float4(s2[0], s2[1], s2[2], s2[3]), p2[1] = make_float4(s2[4], s2[5], s2[6], s2[7]);
     __syncthreads();
     if (tid < 2 * BN) {
       const int q = tid / BN, c = tid % BN;
-      if (n0 + c < g.N) atomicAdd(stats + ((size_t)(blockIdx.x & 7) * 2 + q) * g.N + n0 + c, (double)red[tid]);
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < ORPP; ++r) acc += part[(q * ORPP + r) * BN + c];
+      if (n0 + c < g.N && (g.act & 0x100) == 0)
+        atomicAdd(stats + ((size_t)(blockIdx.x & 7) * 2 + q) * g.N + n0 + c, (double)acc);
     }
   }
 }
@@ -365,9 +362,17 @@ static int ig_dispatch_n(const void* A, const void* Bw, void* C, const float* bi
 template <int VEC, int OVEC, bool GATHER>
 static int ig_dispatch_k(const void* A, const void* Bw, void* C, const float* bias, double* stats, const IGemmGeom& g,
                          hipStream_t stream) {
-  // BK = 64 halves the barriers per MFMA; BK = 32 wastes less on a K that is not a multiple of 64
+  // BK = 64 halves the barriers per MFMA; BK = 32 wastes less on a K that is not a multiple of 64 and, at half the LDS and
+  // 30 fewer VGPRs, lets 4 workgroups share a CU instead of 2 (DFINE_IGEMM_BK=32|64 forces one for A/B measurements)
+  static const int forced = [] {
+    const char* e = getenv("DFINE_IGEMM_BK");
+    return e ? atoi(e) : 0;
+  }();
   const int pad64 = (g.K + 63) / 64 * 64, pad32 = (g.K + 31) / 32 * 32;
-  if (pad64 == pad32 || g.K >= 1024) return ig_dispatch_n<64, VEC, OVEC, GATHER>(A, Bw, C, bias, stats, g, stream);
+  bool use64 = pad64 == pad32 || g.K >= 1024;
+  if (forced == 32) use64 = false;
+  if (forced == 64) use64 = true;
+  if (use64) return ig_dispatch_n<64, VEC, OVEC, GATHER>(A, Bw, C, bias, stats, g, stream);
   return ig_dispatch_n<32, VEC, OVEC, GATHER>(A, Bw, C, bias, stats, g, stream);
 }
 
@@ -387,7 +392,7 @@ extern "C" int dfine_igemm_bf16(const void* A, const void* Bw, void* C, const fl
   if (!A || !Bw || !C || !geom) return DFINE_E_BADARG;
   const IGemmGeom& g = *geom;
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.lda <= 0 || g.ldb < 0 || g.ldc < g.N) return DFINE_E_BADARG;
-  if (g.act != 0 && g.act != 1) return DFINE_E_BADARG;
+  if ((g.act & 0xff) > 1) return DFINE_E_BADARG;  // bit 8: diagnostic, statistics computed but not published
   long long a_extent;  // elements addressed in A (pixel offsets are 32-bit in the kernel)
   if (g.gather) {
     if (g.PH <= 0 || g.PW <= 0 || g.IH <= 0 || g.IW <= 0 || g.CI <= 0 || g.ntaps <= 0 || g.ntaps > DFINE_IGEMM_MAX_TAPS)

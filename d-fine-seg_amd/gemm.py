@@ -57,8 +57,15 @@ def _geom(**kw):
     return g
 
 
+import os as _os
+
+_NO_PUBLISH = bool(_os.environ.get("DFINE_IGEMM_STATS_NOPUBLISH"))  # diagnostic (tools/bench_igemm_cold.py)
+
+
 def _launch(A, Bw, C, bias, stats, g, name, detail):
     lib = _lib.load()
+    if _NO_PUBLISH:
+        g.act |= int(_os.environ["DFINE_IGEMM_STATS_NOPUBLISH"]) << 8
     _lib.require_gpu(A, Bw, C)
     nbytes = (g.M * (g.CI if g.gather else g.K) + g.M * g.N + g.N * g.K) * 2
     with _lib.timed(name, nbytes, detail):

@@ -106,6 +106,127 @@ def test_eval_forward_matches_reference(hip_lib, fname):
         assert _rel(_sample(ev["pred_masks"], 4096)[0], g["eval.pred_masks.sample"]) < 1e-3
 
 
+class _StockOps:
+    """Context manager: every fused / HIP op of ``dfine_seg_amd.ops`` declines or is replaced by the stock PyTorch op, so the
+    SAME modules run as plain PyTorch (F.conv2d, nn.BatchNorm2d, F.relu, LAB, F.linear, SDPA, F.layer_norm) -- under
+    ``torch.autocast`` this is the reference's AMP pipeline on this GPU, the yardstick for the product's bf16 path."""
+
+    def __enter__(self):
+        import torch.nn.functional as F
+
+        from dfine_seg_amd import ops
+
+        names = ("batch_norm_act_supported", "dense_conv", "depthwise_conv2d", "stem_pool_supported", "add_layer_norm_supported",
+                 "linear", "self_attention_supported", "embedding", "conv_transpose2x2")
+        self.ops, self.saved = ops, {n: getattr(ops, n) for n in names}
+        ops.batch_norm_act_supported = lambda x, c: False
+        ops.dense_conv = lambda x, w, stride=1, padding=0, pad_br=None, stats=None, out=None: F.conv2d(
+            F.pad(x, (0, pad_br, 0, pad_br)) if pad_br else x, w, None, stride, padding)
+        ops.depthwise_conv2d = lambda x, w, stride=1: F.conv2d(x, w, None, stride, (w.shape[-1] - 1) // 2, 1, x.shape[1])
+        ops.stem_pool_supported = lambda x: False
+        ops.add_layer_norm_supported = lambda x, d: False
+        ops.linear = lambda x, w, b=None, r0=0, r1=None, relu=False: (F.relu if relu else (lambda t: t))(
+            F.linear(x, w[r0:r1], b[r0:r1] if b is not None else None))
+        ops.self_attention_supported = lambda qk, v, h: False
+        ops.embedding = lambda idx, w, padding_idx=None: F.embedding(idx, w, padding_idx)
+        ops.conv_transpose2x2 = lambda x, w, stats=None: F.conv_transpose2d(x, w, None, 2)
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self.saved.items():
+            setattr(self.ops, n, f)
+        return False
+
+
+def test_bf16_stage_errors_are_bounded_and_below_stock_autocast(hip_lib):
+    """Stage-wise bf16 accuracy of the path that is trained and benchmarked (D-FINE-m, name-hashed weights, the 2-image golden
+    batch; train-mode BatchNorm): each stage is fed the SAME fp32-computed input and its bf16 output is compared with its
+    fp32 output (whose end-to-end agreement with the reference is pinned at 2e-4 above), next to the same modules run as stock
+    PyTorch bf16 autocast. With random weights and a 2-image batch, round-off grows ~7 % per BatchNorm layer in ANY bf16
+    pipeline (profiles/r02_bf16_error_by_layer.txt: stock autocast reaches 1.08 at the end of the backbone and 1.2-1.36 in
+    the encoder; the reference's own 0.27-0.41 in model_m640.npz is its CPU autocast, which keeps BatchNorm outputs in fp32).
+    The product rounds once per layer (conv -> fused norm+act+LAB in fp32 -> bf16) instead of after every op and must stay
+    BELOW the stock pipeline at every stage, and within the absolute bounds written here (measured x 1.5)."""
+    g, model, crit, x, targets, inject, seg = _setup("model_m640")
+    model.train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    xcl = x.contiguous(memory_format=torch.channels_last)
+
+    def stages(autocast):
+        model.load_state_dict(state)  # identical BatchNorm running statistics for every run
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            feats = model.backbone(xcl)
+        return feats
+
+    def encoder_from(feats, autocast):
+        model.load_state_dict(state)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            outs, _ = model.encoder([f.clone() for f in feats])
+        return outs
+
+    feats32 = stages(False)
+    outs32 = encoder_from(feats32, False)
+    feats16 = stages(True)
+    outs16 = encoder_from(feats32, True)  # encoder alone: fed the fp32 features
+    with _StockOps():
+        feats_st = stages(True)
+        outs_st = encoder_from(feats32, True)
+    bounds_backbone, bounds_encoder = (0.12, 0.30, 0.45), (0.75, 0.90, 1.05)
+    for lvl in range(3):
+        e_prod, e_stock = _rel(feats16[lvl].float().cpu(), feats32[lvl].float().cpu()), _rel(feats_st[lvl].float().cpu(), feats32[lvl].float().cpu())
+        assert e_prod < 0.6 * e_stock and e_prod < bounds_backbone[lvl], ("backbone", lvl, e_prod, e_stock)
+        e_prod, e_stock = _rel(outs16[lvl].float().cpu(), outs32[lvl].float().cpu()), _rel(outs_st[lvl].float().cpu(), outs32[lvl].float().cpu())
+        assert e_prod < e_stock and e_prod < bounds_encoder[lvl], ("encoder", lvl, e_prod, e_stock)
+
+
+def test_bf16_train_step_gradients_vs_fp32_and_stock_autocast(hip_lib):
+    """The gradients the benchmarked path feeds its optimizer -- bf16 shadow weights, implicit-GEMM / attention kernels, the
+    wgrad kernels accumulating straight into the flat fp32 gradient buffer (TrainStep, amp=True) -- against (a) the fp32
+    gradients of the same step (pinned to the reference by grad norms above) and (b) the gradients stock PyTorch bf16 autocast
+    + autograd produces for the same modules. D-FINE-s (not n: MIOpen's stock BatchNorm segfaults on n's 21-channel bf16 maps,
+    DESIGN.md 4), reference noise / query selection injected. Bound: cosine similarity
+    with the fp32 gradient >= the stock pipeline's minus 0.03 and >= 0.5, for the whole model and for each of backbone /
+    encoder / decoder. (Measured, whole model: product 0.65, stock autocast 0.59 -- with random weights and BatchNorm over 2
+    images NO bf16 pipeline tracks the fp32 gradient closely, see profiles/r02_bf16_error_by_layer.txt; the product must not be
+    the worse of the two.)"""
+    from dfine_seg_amd.train import TrainStep
+
+    size, img, n_gts, seg = MODEL_CASES["model_s640"]
+    gold = load_golden("model_s640")
+    x = weights.synthetic_images(len(n_gts), img, img, SEED_WEIGHTS_IMG).cuda()
+    targets = weights.synthetic_targets(n_gts, 80, SEED_TARGETS, with_masks=False, height=img, width=img)
+    torch.manual_seed(SEED_CDN)
+    noise = oracle_ops.cdn_noise(n_gts, 80)
+    inject = {"topk_ind": torch.as_tensor(gold["topk_ind"]).cuda(), "cdn_noise": {k: v.cuda() for k, v in noise.items()}}
+
+    def grads(amp, stock):
+        t = TrainStep(size, 80, False, (img, img), "cuda", amp=amp, use_graph=False)
+        sd = weights.fill_state_dict(t.model.state_dict())
+        t.model.load_state_dict(sd, strict=True)
+        t.flat.refresh_bf16_shadow()
+        from dfine_seg_amd.targets import TargetBatch
+
+        tb = TargetBatch.from_list(targets, 80, t.device)
+        if stock:
+            with _StockOps():
+                t._forward_backward(x, tb, inject)
+        else:
+            t._forward_backward(x, tb, inject)
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().float().clone() for n, p in t.model.named_parameters() if p.requires_grad}
+
+    g32, g_prod, g_stock = grads(False, False), grads(True, False), grads(True, True)
+
+    def cos(a, b, prefix=""):
+        names = [n for n in g32 if n.startswith(prefix)]
+        va, vb = torch.cat([a[n].flatten() for n in names]), torch.cat([b[n].flatten() for n in names])
+        return float(torch.dot(va, vb) / (va.norm() * vb.norm()))
+
+    for prefix in ("", "backbone.", "encoder.", "decoder."):
+        c_prod, c_stock = cos(g_prod, g32, prefix), cos(g_stock, g32, prefix)
+        assert c_prod >= 0.5 and c_prod >= c_stock - 0.03, (prefix, c_prod, c_stock)
+
+
 @pytest.mark.parametrize("fname", ["model_m640", "model_m640_seg"])
 def test_bf16_autocast_forward_and_loss(hip_lib, fname):
     """The precision the step is trained and benchmarked in (bf16 autocast; the reference's AMP
@@ -117,9 +238,9 @@ def test_bf16_autocast_forward_and_loss(hip_lib, fname):
     ("bf16ref.*") next to its fp32 ones: encoder maps 27-41 % relative L2 apart, encoder class
     logits 3.9 %, total loss 0.35 %. In that regime the growth of rounding noise through ~60
     BatchNorm layers is chaotic (measured on the MI355X: 0.9 % relative error entering stem2a's
-    BN, 16 % leaving it), so for the encoder maps the test only asks that the product's bf16 run
-    stays correlated with fp32 (relative L2 < 1; measured 0.79-0.95 vs the reference's 0.27-0.41)
-    and is within 2x of the reference's distance on the encoder class logits. The tensors that
+    BN, 16 % leaving it): the encoder maps are bounded stage by stage, against fp32 AND against stock PyTorch bf16
+    autocast on this GPU, in test_bf16_stage_errors_are_bounded_and_below_stock_autocast; here they only have to stay
+    correlated with fp32 end to end, and the encoder class logits within 2x of the reference's own bf16 distance. The tensors that
     matter for training are bounded tightly: final-layer boxes 2e-2 / logits 8e-2 relative L2
     (query selection and denoising noise injected), total loss within 2 % of the fp32
     reference. Kernel-level bf16 accuracy is pinned separately (tests/test_msda.py)."""
@@ -131,9 +252,8 @@ def test_bf16_autocast_forward_and_loss(hip_lib, fname):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         res = model(x, targets=targets, inject=inject)
     hook.remove()
-    for lvl, f in enumerate(grabbed["outs"]):
-        ref_err = _rel(torch.as_tensor(cal[f"bf16ref.encoder.outs.{lvl}.sample"]), cal[f"encoder.outs.{lvl}.sample"])
-        assert _rel(_sample(f)[0], g[f"encoder.outs.{lvl}.sample"]) < max(1.0, 1.5 * ref_err), lvl
+    for lvl, f in enumerate(grabbed["outs"]):  # end-to-end distance to fp32 (bounded stage by stage in the test above)
+        assert _rel(_sample(f)[0], g[f"encoder.outs.{lvl}.sample"]) < 1.1, lvl
     ref_err = _rel(torch.as_tensor(cal["bf16ref.enc0.pred_logits.sample"]), cal["train.enc0.pred_logits.sample"])
     enc_logits = _sample(res["enc_aux_outputs"][0]["pred_logits"], 2048)[0]
     assert _rel(enc_logits, g["train.enc0.pred_logits.sample"]) < 2 * ref_err
