@@ -23,6 +23,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, same guide (not the 2:1-sparsity headline figure)
 
 
 def parse():
@@ -37,8 +38,7 @@ def parse():
     ap.add_argument("--task", default="detect", choices=["detect", "segment"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run every step eagerly (no hipGraph capture)")
-    ap.add_argument("--no-miopen-find", action="store_true",
-                    help="leave torch.backends.cudnn.benchmark off (MIOpen then picks conv solvers by heuristic: ~13 %% slower steps, ~2 min less warm-up)")
+    ap.add_argument("--no-miopen-find", action="store_true", help="(no effect any more: no library convolution is on the path)")
     ap.add_argument("--bucketed-reducer", action="store_true",
                     help="N>1: eager step + bucketed all-reduce from autograd hooks (default: captured graphs, backward in three stages "
                          "whose gradient ranges are all-reduced on a side stream while the next stage replays)")
@@ -102,6 +102,10 @@ TIMER_TO_DEVICE_KERNEL = {
     "fdr_head_fwd": "fdr_head_fwd_kernel", "fdr_head_bwd": "fdr_head_bwd_kernel", "stem_pool_fwd": "pool_fwd_kernel",
     "stem_pool_bwd": "pool_bwd_kernel", "add_layernorm_fwd": "add_ln_fwd_kernel", "add_layernorm_bwd": "add_ln_bwd_kernel",
     "mask_loss_stats": "mask_stats_kernel", "mask_loss_grad": "mask_grad_kernel",
+    # one kernel family behind four call sites: dense conv forward / input gradient, Linear forward / input gradient
+    "conv_fwd": "igemm_kernel", "conv_dgrad": "igemm_kernel", "gemm_fwd": "igemm_kernel", "gemm_dgrad": "igemm_kernel",
+    "attention_fwd": "attn_fwd_kernel", "attention_bwd": "attn_bwd_dkv_kernel", "transpose_weights": "transpose_weights_kernel",
+    "embedding_wgrad": "embedding_wgrad_kernel", "msda_bwd_points": "msda_bwd_kernel", "msda_bwd_value": "msda_bwd_value_kernel",
 }
 
 
@@ -157,10 +161,6 @@ def main():
         # --flat-reducer: one flat all-reduce after backward; --bucketed-reducer: eager step with autograd-hook buckets
         reducer = (ddp.BucketedGradReducer if args.bucketed_reducer else
                    ddp.FlatGradAllReduce if args.flat_reducer else ddp.StagedGradAllReduce)
-    # the library convolutions (dense conv forward / input gradient): let MIOpen time its solvers once per
-    # shape during the warm-up steps instead of trusting its heuristic (which favours split-K kernels that
-    # need a zeroed fp32 workspace and a cast launch around them)
-    torch.backends.cudnn.benchmark = not args.no_miopen_find
     torch.manual_seed(42 + rank)  # per-rank seed like train.py:131
     trainer = TrainStep(args.model, 80, seg, (args.img, args.img), device, total_steps=max(1000, args.steps + args.warmup + 1),
                         grad_reducer=reducer, use_graph=not args.no_graph, graph_masks=not args.no_graph_masks)
@@ -212,17 +212,41 @@ def main():
             kernels[name] = {"launches": st["launches"], "avg_us": round(st["avg_us"], 2),
                              "algorithmic_bytes": int(st["avg_bytes"]), "achieved_GBs": round(gbs, 1),
                              "ms_per_step": round(st["total_ms"] / probe_steps, 3)}
+            if st["total_flops"]:
+                kernels[name]["achieved_TFLOPs"] = round(st["total_flops"] / (st["total_ms"] * 1e-3) / 1e12, 1)
         # HBM-side bytes per launch from the committed PMC passes of this same workload (tools/pmc_traffic.sh:
         # separate FETCH_SIZE and WRITE_SIZE runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950)
         pmc, pmc_file = load_pmc_traffic()
         for name, k in kernels.items():
             dev = TIMER_TO_DEVICE_KERNEL.get(name.split(" ")[0])
             k["traffic_bytes"] = pmc[dev]["traffic_bytes"] if dev in pmc else None
-        # the hand-written kernel the step spends most time in (all of them are HBM/L2-bound)
-        dominant = max(ksum, key=lambda n: ksum[n]["total_ms"])
-        roofline = {"kernel": dominant, "bound": "hbm", "achieved": kernels[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(kernels[dominant]["achieved_GBs"] / HBM_PEAK_GBS, 4),
-                    "traffic": kernels[dominant]["traffic_bytes"], "traffic_source": pmc_file,
+        # the hand-written DEVICE kernel the step spends most time in (timer names that share a kernel are added up: the
+        # implicit-GEMM kernel serves conv forward / input gradient and Linear forward / input gradient). Its roofline:
+        # MFMA when its algorithmic FLOP/s are the larger fraction of their peak, HBM otherwise; `achieved` = algorithmic
+        # work of all its launches / their summed HIP-event durations (= per-launch work / average launch duration).
+        fam = {}
+        for name, st in ksum.items():
+            dev = TIMER_TO_DEVICE_KERNEL.get(name.split(" ")[0], name.split(" ")[0])
+            f = fam.setdefault(dev, {"launches": 0, "total_ms": 0.0, "bytes": 0.0, "flops": 0.0, "call_sites": []})
+            f["launches"] += st["launches"]
+            f["total_ms"] += st["total_ms"]
+            f["bytes"] += st["avg_bytes"] * st["launches"]
+            f["flops"] += st["total_flops"]
+            f["call_sites"].append(name)
+        dominant = max(fam, key=lambda n: fam[n]["total_ms"])
+        d = fam[dominant]
+        secs = d["total_ms"] * 1e-3
+        gbs, tfs = d["bytes"] / secs / 1e9, d["flops"] / secs / 1e12
+        mfma_bound = tfs / MFMA_PEAK_TFLOPS > gbs / HBM_PEAK_GBS
+        roofline = {"kernel": dominant, "call_sites": sorted(set(c.split(" ")[0] for c in d["call_sites"])),
+                    "bound": "mfma" if mfma_bound else "hbm",
+                    "achieved": round(tfs if mfma_bound else gbs, 1), "peak": MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
+                    "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                    "frac": round((tfs / MFMA_PEAK_TFLOPS) if mfma_bound else (gbs / HBM_PEAK_GBS), 4),
+                    "launches_per_step": d["launches"] // probe_steps, "avg_launch_us": round(1e3 * d["total_ms"] / d["launches"], 2),
+                    "ms_per_step": round(d["total_ms"] / probe_steps, 3),
+                    "algorithmic_GBs": round(gbs, 1), "algorithmic_TFLOPs": round(tfs, 1),
+                    "traffic": pmc[dominant]["traffic_bytes"] if dominant in pmc else None, "traffic_source": pmc_file,
                     "timing": f"HIP events over {probe_steps} eager steps run right after the timed region "
                               "(the timed steps replay a hipGraph)" if graph_was_on else "HIP events over eager steps",
                     "kernels": kernels}

@@ -42,6 +42,8 @@ SIGNATURES = {
     "dfine_grad_sumsq": [_c_void_p, ctypes.c_longlong, _c_void_p, _c_void_p],
     "dfine_adamw_ema_step": [_c_void_p] * 8 + [ctypes.POINTER(ctypes.c_longlong), _c_int, ctypes.c_longlong, _c_void_p],
     "dfine_igemm_bf16": [_c_void_p] * 7,
+    "dfine_msda_bwd_points": [_c_void_p, _c_int] + [_c_void_p] * 5 + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
+    "dfine_msda_bwd_value": [_c_int] + [ctypes.POINTER(_c_void_p)] * 3 + [_c_int, _c_void_p] + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
     "dfine_mask_targets_nearest": [_c_void_p, _c_void_p, ctypes.c_longlong] + [_c_int] * 4 + [_c_void_p],
     "dfine_postprocess_topk": [_c_void_p, _c_int] + [_c_void_p] * 6 + [_c_int] * 7 + [_c_void_p],
     "dfine_postprocess_masks": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_int] * 8 + [ctypes.c_float, _c_void_p],
@@ -144,6 +146,7 @@ class KernelTimer:
 
     def __init__(self, by_detail=False):
         self.events = {}
+        self.flops = {}  # name -> algorithmic FLOPs summed over its launches (MFMA kernels)
         self.by_detail = by_detail  # key by "name detail" (e.g. per shape) instead of by name
 
     def summary(self):
@@ -152,7 +155,7 @@ class KernelTimer:
             ms = [a.elapsed_time(b) for a, b, _ in recs]
             nbytes = sum(n for _, _, n in recs)
             out[name] = {"launches": len(ms), "avg_us": 1e3 * sum(ms) / max(len(ms), 1), "total_ms": sum(ms),
-                         "avg_bytes": nbytes / max(len(ms), 1)}
+                         "avg_bytes": nbytes / max(len(ms), 1), "total_flops": self.flops.get(name, 0.0)}
         return out
 
 
@@ -168,8 +171,8 @@ class timed:
     """``with timed("msda_fwd", algorithmic_bytes): launch`` -- a no-op unless a KernelTimer is
     installed. ``nbytes`` is the launch's ALGORITHMIC traffic ("Kernels")."""
 
-    def __init__(self, name, nbytes=0, detail=None):
-        self.name, self.nbytes, self.detail = name, nbytes, detail
+    def __init__(self, name, nbytes=0, detail=None, flops=0.0):
+        self.name, self.nbytes, self.detail, self.flops = name, nbytes, detail, flops
 
     def __enter__(self):
         if _timer is not None:
@@ -182,4 +185,6 @@ class timed:
             stop.record(torch.cuda.current_stream())
             key = f"{self.name} {self.detail}" if (_timer.by_detail and self.detail) else self.name
             _timer.events.setdefault(key, []).append((self.start, stop, self.nbytes))
+            if self.flops:
+                _timer.flops[key] = _timer.flops.get(key, 0.0) + self.flops
         return False

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const T* __restrict__ val
 // for global_atomic_add_f32 on gfx950). grad_attn / grad_loc need a sum over the pair's
 // channels: a shuffle tree over C lanes, written by the pair's first lane.
 // ------------------------------------------------------------------------------------------
-template <typename T, int C>
+template <typename T, int C, bool SCATTER>
 __global__ __launch_bounds__(256) void msda_bwd_kernel(
     const T* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
     const T* __restrict__ grad_out, float* __restrict__ grad_value, float* __restrict__ grad_loc,
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
       }
       // d out / d value: scatter-add, fp32, no return value.
       const float ga_go = go * a;
-      if (live) {
+      if (SCATTER && live) {
         if (b00) atomicAdd(gvbase + o00, ga_go * k.w00);
         if (b01) atomicAdd(gvbase + o01, ga_go * k.w01);
         if (b10) atomicAdd(gvbase + o10, ga_go * k.w10);
@@ -214,7 +214,168 @@ static int launch_fwd(const void* value, const float* loc, const float* attn, vo
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// d(loss)/d(value) WITHOUT global atomics, for every deformable-attention call that sampled the same value
+// tensor (all decoder layers do) in ONE launch. The scatter of the straightforward backward is bound by the
+// chip's float-atomic rate (788 MB of atomic adds per layer at ~1.26 TB/s = 625 us, 4-6 times per step). Here a
+// workgroup owns a SLAB of one level's pixels for one (image, head) -- up to 768 pixels x 32 channels of fp32 =
+// 96 KB of LDS --, scans every (layer, query, point) of that level, adds the corners that fall into its slab
+// with LDS atomics, and finally WRITES the slab (plain 16-byte stores: every element of grad_value is written
+// exactly once, no zero-fill, no read-modify-write). Scanning is cheap (12 bytes per point); the atomic traffic
+// never leaves the CU.
+// ------------------------------------------------------------------------------------------
+constexpr int MSDA_MAX_CALLS = 8;
+constexpr int MSDA_SLAB_FLOATS = 24576;  // 96 KB
+
+struct MsdaCalls {
+  int n;
+  const float* loc[MSDA_MAX_CALLS];
+  const float* attn[MSDA_MAX_CALLS];
+  const void* grad_out[MSDA_MAX_CALLS];
+};
+
+struct MsdaSlabs {
+  int n_slabs;                      // over all levels
+  int first[DFINE_MAX_LEVELS + 1];  // level l owns slabs [first[l], first[l+1])
+  int rows[DFINE_MAX_LEVELS];       // pixel rows per slab of level l
+};
+
+constexpr int MSDA_VALUE_THREADS = 1024;  // 16 waves share one slab: the only latency hiding a 96 KB-LDS workgroup has
+
 template <typename T, int C>
+__global__ __launch_bounds__(MSDA_VALUE_THREADS) void msda_bwd_value_kernel(MsdaCalls calls, float* __restrict__ grad_value, MsdaGeom g,
+                                                                          MsdaSlabs sl, int S, int Lq, int nH) {
+  __shared__ __attribute__((aligned(16))) float tile[MSDA_SLAB_FLOATS];
+  const int slab = blockIdx.x, bh = blockIdx.y, b = bh / nH, h = bh % nH;
+  int l = 0;
+  while (l + 1 < g.n_levels && slab >= sl.first[l + 1]) ++l;
+  const int H = g.H[l], W = g.W[l];
+  const int y_begin = (slab - sl.first[l]) * sl.rows[l], y_end = min(y_begin + sl.rows[l], H);
+  const int n_px = (y_end - y_begin) * W;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = MSDA_VALUE_THREADS / 64;
+  for (int i = tid * 4; i < n_px * C; i += MSDA_VALUE_THREADS * 4) *reinterpret_cast<float4*>(tile + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  constexpr int SUBS = 64 / C;  // lane groups of C channels: 2 (C = 32) or 4 (C = 16)
+  const int ch = lane % C, sub = lane / C;
+  const int p0 = g.pt_begin[l], n_pt = g.pt_begin[l + 1] - p0;
+  const int n_pairs = Lq * n_pt;
+  for (int c = 0; c < calls.n; ++c) {
+    const float* loc = calls.loc[c];
+    const float* attn = calls.attn[c];
+    const T* go_base = reinterpret_cast<const T*>(calls.grad_out[c]);
+    // a wave takes 64 (query, point) pairs at a time: every lane decodes ONE pair (coalesced-ish 8-byte loads, one memory
+    // latency per 64 pairs), then the wave walks the pairs that touch this slab, four at a time so that the four
+    // grad_out rows they need are in flight together
+    for (int base = wave * 64; base < n_pairs; base += NW * 64) {
+      const int idx = base + lane;
+      bool hit = false;
+      int r_up = 0, r_dn = 0, x_step = 0;
+      float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+      int pair32 = 0;  // (image, query, head) index: < 2^31 / C, checked on the host
+      if (idx < n_pairs) {
+        const int q = idx / n_pt, p = p0 + idx - q * n_pt;
+        const size_t pair = ((size_t)b * Lq + q) * nH + h;
+        pair32 = (int)pair;
+        const float2 xy = *reinterpret_cast<const float2*>(loc + (pair * g.P + p) * 2);
+        const Corners k = make_corners(xy.x, xy.y, H, W, 0);
+        const int y0 = k.r00 / W, y1 = k.r10 / W;  // exact: r = y*W + x with x < W
+        const bool in0 = k.vy0 && y0 >= y_begin && y0 < y_end, in1 = k.vy1 && y1 >= y_begin && y1 < y_end;
+        hit = in0 || in1;
+        if (hit) {
+          const float a = attn[pair * g.P + p];
+          w00 = in0 ? a * k.w00 : 0.f, w01 = in0 ? a * k.w01 : 0.f;
+          w10 = in1 ? a * k.w10 : 0.f, w11 = in1 ? a * k.w11 : 0.f;
+          // rows are clamped into the slab when their weight is zero (no add is issued for a zero weight)
+          r_up = in0 ? k.r00 - y_begin * W : 0;
+          r_dn = in1 ? k.r10 - y_begin * W : 0;
+          x_step = k.r01 - k.r00;  // 0 or 1 (the right neighbour; 0 at the border, where its weight is 0)
+        }
+      }
+      unsigned long long todo = __ballot(hit);
+      while (todo) {
+        int j[4];
+        float go[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          j[u] = todo ? __ffsll((long long)todo) - 1 : -1;
+          if (todo) todo &= todo - 1;
+        }
+        // broadcasts are scalar reads of one lane (v_readlane with a wave-uniform index), not LDS shuffles: with 16 waves
+        // adding into the slab the LDS pipe is the kernel's bottleneck
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          go[u] = 0.f;
+          if (j[u] >= 0) {
+            const int ju = __builtin_amdgcn_readfirstlane(j[u]);
+            const int pj = __builtin_amdgcn_readlane(pair32, ju);
+            go[u] = VecTraits<T>::load1(go_base + (size_t)pj * C + ch);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (j[u] < 0) continue;
+          const int ju = __builtin_amdgcn_readfirstlane(j[u]);
+          const int ru = __builtin_amdgcn_readlane(r_up, ju), rd = __builtin_amdgcn_readlane(r_dn, ju);
+          const int xs = __builtin_amdgcn_readlane(x_step, ju);
+          const float a00 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w00), ju));
+          const float a01 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w01), ju));
+          const float a10 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w10), ju));
+          const float a11 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w11), ju));
+          if (SUBS == 2) {  // sub 0: the upper corner pair, sub 1: the lower one
+            const int r = sub == 0 ? ru : rd;
+            const float wa = sub == 0 ? a00 : a10, wb = sub == 0 ? a01 : a11;
+            if (wa != 0.f) atomicAdd(tile + r * C + ch, go[u] * wa);
+            if (wb != 0.f) atomicAdd(tile + (r + xs) * C + ch, go[u] * wb);
+          } else {  // one corner per lane group
+            const int r = (sub < 2 ? ru : rd) + ((sub & 1) ? xs : 0);
+            const float w = sub == 0 ? a00 : sub == 1 ? a01 : sub == 2 ? a10 : a11;
+            if (w != 0.f) atomicAdd(tile + r * C + ch, go[u] * w);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // flush: pixel px of the slab -> grad_value[b][start + y_begin*W + px][h][0..C)
+  float* out = grad_value + (((size_t)b * S + g.start[l] + (size_t)y_begin * W) * nH + h) * C;
+  constexpr int V4 = C / 4;
+  for (int i = tid; i < n_px * V4; i += MSDA_VALUE_THREADS) {
+    const int px = i / V4, v = i - px * V4;
+    *reinterpret_cast<float4*>(out + (size_t)px * nH * C + v * 4) = *reinterpret_cast<const float4*>(tile + px * C + v * 4);
+  }
+}
+
+template <int C>
+static bool make_slabs(const MsdaGeom& g, MsdaSlabs* sl) {
+  int n = 0;
+  for (int l = 0; l < g.n_levels; ++l) {
+    const int max_px = MSDA_SLAB_FLOATS / C;
+    if (g.W[l] > max_px) return false;  // a single pixel row does not fit: the atomic kernel handles this map
+    const int n_l = (g.H[l] * g.W[l] + max_px - 1) / max_px;
+    int rows = (g.H[l] + n_l - 1) / n_l;
+    while (rows * g.W[l] > max_px) --rows;
+    sl->first[l] = n;
+    sl->rows[l] = rows;
+    n += (g.H[l] + rows - 1) / rows;
+  }
+  sl->first[g.n_levels] = n;
+  sl->n_slabs = n;
+  return true;
+}
+
+template <typename T, int C>
+static int launch_bwd_value(const MsdaCalls& calls, float* grad_value, const MsdaGeom& g, int B, int S, int Lq, int nH,
+                            hipStream_t st) {
+  MsdaSlabs sl;
+  if (!make_slabs<C>(g, &sl)) return DFINE_E_UNSUPPORTED;
+  if ((long long)B * nH > 65535 || (long long)B * Lq * nH * C > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
+  hipLaunchKernelGGL((msda_bwd_value_kernel<T, C>), dim3(sl.n_slabs, B * nH), dim3(MSDA_VALUE_THREADS), 0, st, calls, grad_value, g, sl, S, Lq, nH);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int C, bool SCATTER = true>
 static int launch_bwd(const void* value, const float* loc, const float* attn,
                       const void* grad_out, float* grad_value, float* grad_loc, float* grad_attn,
                       const MsdaGeom& g, int B, int S, int Lq, int nH, hipStream_t st) {
@@ -223,7 +384,7 @@ static int launch_bwd(const void* value, const float* loc, const float* attn,
   const int block = 256;
   const long long grid = (threads + block - 1) / block;
   if (grid > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
-  hipLaunchKernelGGL((msda_bwd_kernel<T, C>), dim3((unsigned)grid), dim3(block), 0, st,
+  hipLaunchKernelGGL((msda_bwd_kernel<T, C, SCATTER>), dim3((unsigned)grid), dim3(block), 0, st,
                      (const T*)value, loc, attn, (const T*)grad_out, grad_value, grad_loc,
                      grad_attn, g, (int)n_pairs, S, Lq, nH);
   DFINE_LAUNCH_CHECK();
@@ -280,5 +441,47 @@ extern "C" int dfine_msda_bwd(const void* value, int value_dtype, const float* l
   if (value_dtype == DFINE_DT_F32 && c == 16)
     return launch_bwd<float, 16>(value, loc, attn, grad_out, grad_value, grad_loc, grad_attn, g,
                                  B, S, Lq, nH, st);
+  return DFINE_E_UNSUPPORTED;
+}
+
+// grad_loc / grad_attn only (the value gradient is left to dfine_msda_bwd_value)
+extern "C" int dfine_msda_bwd_points(const void* value, int value_dtype, const float* loc, const float* attn, const void* grad_out,
+                                     float* grad_loc, float* grad_attn, int B, int S, int Lq, int nH, int c, int n_levels,
+                                     const int32_t* level_hw, const int32_t* num_points, void* stream) {
+  if (!value || !loc || !attn || !grad_out || !grad_loc || !grad_attn || !level_hw || !num_points) return DFINE_E_BADARG;
+  if (B <= 0 || S <= 0 || Lq <= 0 || nH <= 0) return DFINE_E_BADARG;
+  MsdaGeom g;
+  if (int rc = make_geom(&g, S, n_levels, level_hw, num_points)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (value_dtype == DFINE_DT_BF16 && c == 32)
+    return launch_bwd<bf16_t, 32, false>(value, loc, attn, grad_out, nullptr, grad_loc, grad_attn, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_BF16 && c == 16)
+    return launch_bwd<bf16_t, 16, false>(value, loc, attn, grad_out, nullptr, grad_loc, grad_attn, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_F32 && c == 32)
+    return launch_bwd<float, 32, false>(value, loc, attn, grad_out, nullptr, grad_loc, grad_attn, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_F32 && c == 16)
+    return launch_bwd<float, 16, false>(value, loc, attn, grad_out, nullptr, grad_loc, grad_attn, g, B, S, Lq, nH, st);
+  return DFINE_E_UNSUPPORTED;
+}
+
+extern "C" int dfine_msda_bwd_value(int value_dtype, const void* const* loc, const void* const* attn, const void* const* grad_out,
+                                    int n_calls, float* grad_value, int B, int S, int Lq, int nH, int c, int n_levels,
+                                    const int32_t* level_hw, const int32_t* num_points, void* stream) {
+  if (!loc || !attn || !grad_out || !grad_value || !level_hw || !num_points) return DFINE_E_BADARG;
+  if (n_calls <= 0 || B <= 0 || S <= 0 || Lq <= 0 || nH <= 0) return DFINE_E_BADARG;
+  if (n_calls > MSDA_MAX_CALLS) return DFINE_E_UNSUPPORTED;
+  MsdaGeom g;
+  if (int rc = make_geom(&g, S, n_levels, level_hw, num_points)) return rc;
+  MsdaCalls calls;
+  calls.n = n_calls;
+  for (int i = 0; i < n_calls; ++i) {
+    if (!loc[i] || !attn[i] || !grad_out[i]) return DFINE_E_BADARG;
+    calls.loc[i] = (const float*)loc[i], calls.attn[i] = (const float*)attn[i], calls.grad_out[i] = grad_out[i];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (value_dtype == DFINE_DT_BF16 && c == 32) return launch_bwd_value<bf16_t, 32>(calls, grad_value, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_BF16 && c == 16) return launch_bwd_value<bf16_t, 16>(calls, grad_value, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_F32 && c == 32) return launch_bwd_value<float, 32>(calls, grad_value, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_F32 && c == 16) return launch_bwd_value<float, 16>(calls, grad_value, g, B, S, Lq, nH, st);
   return DFINE_E_UNSUPPORTED;
 }

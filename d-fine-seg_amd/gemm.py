@@ -68,7 +68,7 @@ def _launch(A, Bw, C, bias, stats, g, name, detail):
         g.act |= int(_os.environ["DFINE_IGEMM_STATS_NOPUBLISH"]) << 8
     _lib.require_gpu(A, Bw, C)
     nbytes = (g.M * (g.CI if g.gather else g.K) + g.M * g.N + g.N * g.K) * 2
-    with _lib.timed(name, nbytes, detail):
+    with _lib.timed(name, nbytes, detail, flops=2.0 * g.M * g.N * g.K):
         rc = lib.dfine_igemm_bf16(_lib.ptr(A), _lib.ptr(Bw), _lib.ptr(C), _lib.ptr(bias), _lib.ptr(stats), ctypes.byref(g),
                                   _lib.stream_ptr())
     _lib.check(rc, "dfine_igemm_bf16")

@@ -2,6 +2,7 @@
 HIP kernels from libdfine_hip.so. Names and argument meaning follow the reference's own
 operator seams so the parity tests read like calls into the reference.
 """
+import ctypes
 from typing import List, Sequence
 
 import torch
@@ -99,55 +100,125 @@ class _MSDeformAttnCore(torch.autograd.Function):
         B, S, nH, c = value.shape
         Lq = loc.shape[1]
         grad_out = grad_out.to(value.dtype).contiguous()
-        sink = ctx.sink
-        if sink is not None and sink.buffer is not None:
-            grad_value = sink.buffer  # keep accumulating: every decoder layer samples the same value
-        else:
-            grad_value = torch.zeros(B, S, nH, c, dtype=torch.float32, device=value.device)
-            if sink is not None:
-                sink.buffer = grad_value
         grad_loc = torch.empty_like(loc)
         grad_attn = torch.empty_like(attn)
         hw = _lib.i32_array(v for pair in level_hw for v in pair)
         npts = _lib.i32_array(num_points)
-        with _lib.timed("msda_bwd", msda_algorithmic_bytes(B, Lq, nH, loc.shape[3], c, value.element_size())[1]):
-            rc = lib.dfine_msda_bwd(
-                _lib.ptr(value), _lib.dtype_code(value), _lib.ptr(loc), _lib.ptr(attn),
-                _lib.ptr(grad_out), _lib.ptr(grad_value), _lib.ptr(grad_loc), _lib.ptr(grad_attn),
-                B, S, Lq, nH, c, len(num_points), hw, npts, _lib.stream_ptr(),
-            )
-        _lib.check(rc, "dfine_msda_bwd")
-        if sink is not None:
-            if not ctx.finalize:
+        sink = ctx.sink
+        if MSDA_VALUE_GRAD == "atomic":
+            # one kernel: grad_loc / grad_attn and the value gradient scattered with global float atomics into ONE fp32 buffer
+            # shared by every call that samples this value tensor (measured faster than the LDS-slab variant below: the
+            # chip's LDS float-atomic rate, ~0.18 T adds/s, is LOWER than its global one, ~0.31 T adds/s)
+            if sink is not None and sink.buffer is not None:
+                grad_value = sink.buffer
+            else:
+                grad_value = torch.zeros(B, S, nH, c, dtype=torch.float32, device=value.device)
+                if sink is not None:
+                    sink.buffer = grad_value
+            with _lib.timed("msda_bwd", msda_algorithmic_bytes(B, Lq, nH, loc.shape[3], c, value.element_size())[1]):
+                rc = lib.dfine_msda_bwd(
+                    _lib.ptr(value), _lib.dtype_code(value), _lib.ptr(loc), _lib.ptr(attn), _lib.ptr(grad_out), _lib.ptr(grad_value),
+                    _lib.ptr(grad_loc), _lib.ptr(grad_attn), B, S, Lq, nH, c, len(num_points), hw, npts, _lib.stream_ptr())
+            _lib.check(rc, "dfine_msda_bwd")
+            if sink is not None and not ctx.finalize:
                 sink.expect_consumer()
                 return None, grad_loc, grad_attn, None, None, None, None
-            sink.buffer = None
-        return grad_value.to(value.dtype), grad_loc, grad_attn, None, None, None, None
+            if sink is not None:
+                sink.buffer = None
+            return grad_value.to(value.dtype), grad_loc, grad_attn, None, None, None, None
+        fwd_bytes = msda_algorithmic_bytes(B, Lq, nH, loc.shape[3], c, value.element_size())[0]
+        with _lib.timed("msda_bwd_points", fwd_bytes + 2 * loc.numel() * 4):
+            rc = lib.dfine_msda_bwd_points(
+                _lib.ptr(value), _lib.dtype_code(value), _lib.ptr(loc), _lib.ptr(attn), _lib.ptr(grad_out),
+                _lib.ptr(grad_loc), _lib.ptr(grad_attn), B, S, Lq, nH, c, len(num_points), hw, npts, _lib.stream_ptr())
+        _lib.check(rc, "dfine_msda_bwd_points")
+        # d(loss)/d(value): deferred to ONE atomic-free launch over every call that sampled this value tensor
+        sink = ctx.sink if ctx.sink is not None else ValueGradSink()
+        sink.add(value, loc, attn, grad_out, level_hw, num_points)
+        if ctx.sink is not None and not ctx.finalize:
+            sink.expect_consumer()
+            return None, grad_loc, grad_attn, None, None, None, None
+        return sink.flush().to(value.dtype), grad_loc, grad_attn, None, None, None, None
+
+
+# How d(loss)/d(value) of the deformable attention is formed: "atomic" = global float atomics inside the backward kernel
+# (default, faster on MI355X), "slab" = deferred, one dfine_msda_bwd_value launch over all calls (LDS slabs, no global atomics,
+# bitwise reproducible). DFINE_MSDA_VALUE=slab selects the latter.
+import os as _os
+
+MSDA_VALUE_GRAD = "slab" if _os.environ.get("DFINE_MSDA_VALUE", "") == "slab" else "atomic"
 
 
 class ValueGradSink:
-    """Shared fp32 accumulator for d(loss)/d(value) when several deformable-attention calls sample the
-    SAME value tensor (all decoder layers do, dfine_decoder.py:449): every call's backward adds its
-    float atomics into one buffer; the call made FIRST in the forward pass (``finalize=True``: its
-    backward runs last) converts it once and hands it to autograd, the others return no value gradient."""
+    """d(loss)/d(value) when several deformable-attention calls sample the SAME value tensor (all decoder layers do,
+    dfine_decoder.py:449): every call's backward computes its own grad_loc / grad_attn and parks (loc, attn, grad_out)
+    here; ``flush()`` -- called by the call made FIRST in the forward pass (``finalize=True``: its backward runs last) or by
+    ``select_rows`` -- turns all of them into the fp32 value gradient with ONE launch of dfine_msda_bwd_value (LDS slabs,
+    no global atomics, every element written once)."""
 
     def __init__(self):
-        self.buffer = None
+        self.pending = []   # "slab" mode: parked (loc, attn, grad_out) triples
+        self.buffer = None  # "atomic" mode: the shared fp32 accumulator
+        self.meta = None
         self._check_queued = False
 
+    def add(self, value, loc, attn, grad_out, level_hw, num_points):
+        meta = (tuple(value.shape), value.dtype, value.device, level_hw, num_points, loc.shape[1])
+        if self.meta is not None and self.meta != meta:
+            raise RuntimeError("ValueGradSink: calls with different value tensors / geometry share one sink")
+        self.meta = meta
+        self.pending.append((loc, attn, grad_out))
+
+    def flush(self):
+        """fp32 [B, S, nH, c] gradient of every call so far (None if there was none); empties the sink."""
+        if self.buffer is not None:
+            total, self.buffer = self.buffer, None
+            return total
+        if not self.pending:
+            return None
+        (B, S, nH, c), dtype, device, level_hw, num_points, Lq = self.meta
+        lib = _lib.load()
+        hw = _lib.i32_array(v for pair in level_hw for v in pair)
+        npts = _lib.i32_array(num_points)
+        code = _lib.DT_BF16 if dtype == torch.bfloat16 else _lib.DT_F32
+        P = sum(num_points)
+        total = None
+        for first in range(0, len(self.pending), 8):  # the kernel takes up to 8 calls per launch
+            chunk = self.pending[first : first + 8]
+            n = len(chunk)
+            arr = lambda k: (ctypes.c_void_p * n)(*[t[k].data_ptr() for t in chunk])
+            part = torch.empty(B, S, nH, c, dtype=torch.float32, device=device)
+            nbytes = n * B * Lq * nH * (P * 12 + c * (2 if dtype == torch.bfloat16 else 4)) + part.numel() * 4
+            with _lib.timed("msda_bwd_value", nbytes):
+                rc = lib.dfine_msda_bwd_value(code, arr(0), arr(1), arr(2), n, _lib.ptr(part), B, S, Lq, nH, c, len(num_points), hw, npts,
+                                              _lib.stream_ptr())
+            if rc == -2:  # a level too wide for an LDS slab: the float-atomic kernel
+                part.zero_()
+                for loc, attn, go in chunk:
+                    scratch_l, scratch_a = torch.empty_like(loc), torch.empty_like(attn)
+                    dummy_value = torch.zeros(B, S, nH, c, dtype=dtype, device=device)
+                    rc2 = lib.dfine_msda_bwd(_lib.ptr(dummy_value), code, _lib.ptr(loc), _lib.ptr(attn), _lib.ptr(go), _lib.ptr(part),
+                                             _lib.ptr(scratch_l), _lib.ptr(scratch_a), B, S, Lq, nH, c, len(num_points), hw, npts,
+                                             _lib.stream_ptr())
+                    _lib.check(rc2, "dfine_msda_bwd")
+            else:
+                _lib.check(rc, "dfine_msda_bwd_value")
+            total = part if total is None else total.add_(part)
+        self.pending, self.meta = [], None
+        return total
+
     def expect_consumer(self):
-        """Called from a non-finalizing backward: somebody else (``select_rows``) must take the buffer
-        before this backward pass ends. If nobody does the value gradient would be silently lost, so
-        the end-of-backward callback raises instead."""
+        """Called from a non-finalizing backward: somebody else (``select_rows``) must flush the sink before this backward
+        pass ends. If nobody does the value gradient would be silently lost, so the end-of-backward callback raises."""
         if not self._check_queued:
             self._check_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self._check)
 
     def _check(self):
         self._check_queued = False
-        if self.buffer is not None:
-            self.buffer = None
-            raise RuntimeError("deformable attention: d(loss)/d(value) was accumulated but never handed to autograd "
+        if self.pending or self.buffer is not None:
+            self.pending, self.meta, self.buffer = [], None, None
+            raise RuntimeError("deformable attention: d(loss)/d(value) was parked but never handed to autograd "
                                "(finalize=False on every call and no select_rows() on the backward path)")
 
 
@@ -174,11 +245,9 @@ class _SelectRows(torch.autograd.Function):
         idx_e, scale = ctx.saved_tensors
         B, S, D = ctx.shape
         sink = ctx.sink
-        total = sink.buffer if sink is not None else None
+        total = sink.flush() if sink is not None else None  # every deformable-attention call's value gradient, one launch
         if total is None:
             total = torch.zeros(B, S, D, dtype=torch.float32, device=g.device)
-        elif sink is not None:
-            sink.buffer = None
         total.view(B, S, D).scatter_add_(1, idx_e, (g * scale).float())
         return total.view(B, S, D).to(ctx.dtype), None, None, None
 
@@ -787,7 +856,7 @@ class _Linear(torch.autograd.Function):
         else:
             dw = torch.zeros(N, K, dtype=torch.float32, device=x2.device)
             db = torch.zeros(N, dtype=torch.float32, device=x2.device) if bias is not None else None
-        with _lib.timed("wgrad", (M * N + M * K) * 2 + N * K * 4, f"linear M{M} N{N} K{K}"):
+        with _lib.timed("wgrad", (M * N + M * K) * 2 + N * K * 4, f"linear M{M} N{N} K{K}", flops=2.0 * M * N * K):
             rc = lib.dfine_linear_wgrad(_lib.ptr(gy16), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), M, N, K, K, N, K, _lib.stream_ptr())
         _lib.check(rc, "dfine_linear_wgrad")
         if direct:
@@ -874,7 +943,7 @@ class _DenseConv(torch.autograd.Function):
             dw = torch.zeros(K_out, C_in, KH, KW, dtype=torch.float32, device=xl.device).contiguous(memory_format=torch.channels_last)
         M = B * OH * OW
         with _lib.timed("wgrad", (M * K_out + xc.numel()) * 2 + K_out * C_in * taps * 4,
-                        f"conv {B}x{H}x{W} {C_in}->{K_out} k{KH}s{stride}"):
+                        f"conv {B}x{H}x{W} {C_in}->{K_out} k{KH}s{stride}", flops=2.0 * M * K_out * C_in * taps):
             rc = lib.dfine_conv_wgrad(_lib.ptr(gyc), _lib.ptr(xc), _lib.ptr(dw), B, H, W, C_in, OH, OW, K_out, KH, KW,
                                       stride, padding, ldy, ldx, _lib.stream_ptr())
         _lib.check(rc, "dfine_conv_wgrad")

@@ -423,6 +423,23 @@ int dfine_postprocess_masks(const void* probs, int dtype, const long long* qidx,
 int dfine_mask_targets_nearest(const unsigned char* masks, float* out, long long n_maps, int H, int W, int Hm, int Wm,
                                void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Deformable-attention backward split so that the value gradient needs no global atomics:
+ * dfine_msda_bwd_points = dfine_msda_bwd without its grad_value scatter (grad_loc, grad_attn only);
+ * dfine_msda_bwd_value: d(loss)/d(value) of n_calls deformable-attention calls that sampled the SAME value
+ *   tensor (every decoder layer does, dfine_decoder.py:449) in one launch: loc[i] f32 [B, Lq, nH, P, 2], attn[i] f32
+ *   [B, Lq, nH, P], grad_out[i] [B, Lq, nH*c] in value's dtype -- host arrays of n_calls device pointers (<= 8) --
+ *   -> grad_value f32 [B, S, nH, c], WRITTEN (every element exactly once: no zero fill, nothing accumulated).
+ *   Workgroups own slabs of one level's pixels for one (image, head) in LDS and add with LDS atomics.
+ *   DFINE_E_UNSUPPORTED when a single pixel row of a level exceeds the 96 KB slab (use dfine_msda_bwd then).
+ * ------------------------------------------------------------------------------------- */
+int dfine_msda_bwd_points(const void* value, int value_dtype, const float* loc, const float* attn, const void* grad_out,
+                          float* grad_loc, float* grad_attn, int B, int S, int Lq, int nH, int c, int n_levels,
+                          const int32_t* level_hw, const int32_t* num_points, void* stream);
+int dfine_msda_bwd_value(int value_dtype, const void* const* loc /* host */, const void* const* attn /* host */,
+                         const void* const* grad_out /* host */, int n_calls, float* grad_value, int B, int S, int Lq, int nH,
+                         int c, int n_levels, const int32_t* level_hw, const int32_t* num_points, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

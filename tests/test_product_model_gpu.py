@@ -266,3 +266,33 @@ def test_bf16_autocast_forward_and_loss(hip_lib, fname):
     assert abs(total - ref_total) <= 2e-2 * abs(ref_total), (total, ref_total)
     sum(losses.values()).backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_x960_full_size_step_properties(hip_lib):
+    """BASELINE config 5 at its real size (D-FINE-x, 960x960: 18 900 memory tokens, 900 AIFI tokens with 48-wide heads, 384-wide
+    encoder with the 384 -> 256 decoder projection, frozen backbone BatchNorm, 6 decoder layers), batch 2, through the full
+    bf16 training step and the eval forward -- size-independent properties instead of a golden (the x fixture is 640x640):
+    finite loss terms with the reference's 68 keys, finite weights after the fused optimizer, gradients zeroed, the 384-wide
+    LayerNorm on the HIP kernel, eval outputs finite, boxes inside the image, and two eval runs bit-identical."""
+    from dfine_seg_amd import ops
+    from dfine_seg_amd.synth import synthetic_batch
+    from dfine_seg_amd.train import TrainStep
+
+    torch.manual_seed(0)
+    t = TrainStep("x", 80, False, (960, 960), "cuda", amp=True, use_graph=False, total_steps=100)
+    images, targets = synthetic_batch(2, 960, 960, 80, 8, seed=3, device="cuda")
+    assert ops.add_layer_norm_supported(torch.empty(2, 900, 384, device="cuda", dtype=torch.bfloat16), 384)
+    for _ in range(2):
+        loss = t.step(images, targets)
+    assert torch.isfinite(loss)
+    assert len(t.last_losses) == 68 and all(torch.isfinite(v) for v in t.last_losses.values())
+    assert torch.isfinite(t.flat.params).all() and float(t.flat.grads.abs().max()) == 0.0
+    assert torch.equal(t.flat.shadow, t.flat.params.to(torch.bfloat16))
+    t.model.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        a = t.model(images)
+        b = t.model(images)
+    assert a["pred_logits"].shape == (2, 300, 80) and a["pred_boxes"].shape == (2, 300, 4)
+    assert torch.isfinite(a["pred_logits"].float()).all() and torch.isfinite(a["pred_boxes"]).all()
+    assert float(a["pred_boxes"].min()) >= -1e-3 and float(a["pred_boxes"].max()) <= 1.5
+    assert torch.equal(a["pred_logits"], b["pred_logits"]) and torch.equal(a["pred_boxes"], b["pred_boxes"])

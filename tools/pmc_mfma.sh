@@ -1,11 +1,11 @@
 #!/bin/bash
-# MFMA utilisation of the GEMM/conv kernels of the step (this repo's wgrad, MIOpen igemm/CK, hipBLASLt):
+# MFMA utilisation of the contraction kernels of the step (this repo's igemm / wgrad / attention; any library GEMM left):
 #   util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)
 #   bash tools/pmc_mfma.sh gpurun_out/mfmaN
 out=$GRAFT_REPO_ROOT/$1
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --kernel-include-regex "wgrad|igemm|Cijk|xdl|attn|bwd_kernel" --output-format csv -d $out/pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 3 --no-cpu-baseline --no-graph > $out/pmc.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --kernel-include-regex "wgrad|igemm|Cijk|xdl|attn|bwd_kernel|adamw" --output-format csv -d $out/pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 3 --no-cpu-baseline --no-graph > $out/pmc.log 2>&1
 cd $GRAFT_REPO_ROOT
 python - <<PY > $out/mfma_util.json
 import csv, glob, json, collections, re
@@ -14,16 +14,19 @@ for f in glob.glob("$out/pmc/*/*counter_collection.csv"):
     rows += list(csv.DictReader(open(f)))
 # only the LAST step (MIOpen's find-mode trials run in the first steps): everything dispatched after the
 # previous step's last wgrad launch
-wg = sorted({int(r["Dispatch_Id"]) for r in rows if "wgrad_kernel" in r["Kernel_Name"]})
-per_step = 184
-start = wg[-per_step - 1] if len(wg) > per_step else 0
+# the LAST step only: everything dispatched after the second-to-last adamw launch (one per step)
+opt = sorted({int(r["Dispatch_Id"]) for r in rows if "adamw" in r["Kernel_Name"]})
+start = opt[-2] if len(opt) > 1 else 0
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 for r in rows:
     if int(r["Dispatch_Id"]) <= start:
         continue
     n = r["Kernel_Name"]
-    if "wgrad_kernel" in n: k = "dfine::wgrad_kernel (this repo)"
+    if "wgrad_kernel" in n: k = "dfine::wgrad_kernel (weight gradients)"
+    elif "dfine::igemm_kernel" in n and "true>" in n.split("(")[0]: k = "dfine::igemm_kernel, gathered (k x k / strided conv forward + input gradient)"
+    elif "dfine::igemm_kernel" in n: k = "dfine::igemm_kernel, plain rows (1x1 conv + Linear forward / input gradient)"
+    elif "dfine::attn" in n: k = "dfine::attn_* (self-attention forward / backward)"
     elif "igemm_fwd" in n or "conv_fwd" in n: k = "MIOpen conv forward (igemm asm / CK xdl)"
     elif "igemm_bwd" in n or "conv_bwd_data" in n: k = "MIOpen conv input-gradient (igemm asm / CK xdl)"
     elif "igemm_wrw" in n or "conv_bwd_weight" in n: k = "MIOpen conv weight-gradient (stem convs with 3 / 12 input channels)"

@@ -6,7 +6,7 @@ out=$GRAFT_REPO_ROOT/$1
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "dfine" --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 3 --no-cpu-baseline --no-graph --no-miopen-find > $out/$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "dfine" --output-format csv -d $out/$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 3 --no-cpu-baseline --no-graph > $out/$c.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
 python tools/pmc_summarize.py $out > $out/pmc_traffic.json
