@@ -775,6 +775,49 @@ def fdr_head(corners, ref_boxes, W, reg_scale, k=4):
     return _FdrHead.apply(corners, ref_boxes, W, float(reg_scale), int(k))
 
 
+# Weight-gradient kernels on a SIDE stream. In backward a layer's weight gradient and its input gradient both consume dY and
+# are independent of each other; the weight gradients are needed only by the optimizer at the end of the step. With a side
+# stream installed (``TrainStep`` does) every wgrad launch forks from the current stream, runs beside the dgrad / BatchNorm
+# chain of the layers below, and the step joins once before the optimizer (``join_wgrad``). Under graph capture the fork /
+# join become graph edges, so the replayed graph has two parallel branches: the tails of the ~1 000 small backward kernels
+# (most of which do not fill 256 CUs) overlap. Operands are ``record_stream``-ed so the allocator does not recycle them early.
+wgrad_stream = None
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+class on_wgrad_stream:
+    def __init__(self, *tensors):
+        self.tensors = tensors
+
+    def __enter__(self):
+        self.ctx = None
+        if wgrad_stream is not None:
+            wgrad_stream.wait_stream(torch.cuda.current_stream())
+            for t in self.tensors:
+                if t is not None:
+                    t.record_stream(wgrad_stream)
+            self.ctx = torch.cuda.stream(wgrad_stream)
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_wgrad():
+    """The current stream waits for every weight-gradient launch forked so far."""
+    if wgrad_stream is not None:
+        torch.cuda.current_stream().wait_stream(wgrad_stream)
+
+
 # Accumulate Linear weight gradients straight into ``param.grad`` (the flat fp32 gradient buffer) and
 # hand autograd ``None`` for them -- the same contract as a fused wgrad-accumulate GEMM. Switched off
 # by the data-parallel reducer, which counts post-accumulate hooks to know when a bucket is complete.
@@ -856,8 +899,9 @@ class _Linear(torch.autograd.Function):
         else:
             dw = torch.zeros(N, K, dtype=torch.float32, device=x2.device)
             db = torch.zeros(N, dtype=torch.float32, device=x2.device) if bias is not None else None
-        with _lib.timed("wgrad", (M * N + M * K) * 2 + N * K * 4, f"linear M{M} N{N} K{K}", flops=2.0 * M * N * K):
-            rc = lib.dfine_linear_wgrad(_lib.ptr(gy16), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), M, N, K, K, N, K, _lib.stream_ptr())
+        with on_wgrad_stream(gy16, x2 if direct else None) if direct else _NullCtx():
+            with _lib.timed("wgrad", (M * N + M * K) * 2 + N * K * 4, f"linear M{M} N{N} K{K}", flops=2.0 * M * N * K):
+                rc = lib.dfine_linear_wgrad(_lib.ptr(gy16), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), M, N, K, K, N, K, _lib.stream_ptr())
         _lib.check(rc, "dfine_linear_wgrad")
         if direct:
             return dx, None, None, None, None, None
@@ -942,10 +986,11 @@ class _DenseConv(torch.autograd.Function):
         else:
             dw = torch.zeros(K_out, C_in, KH, KW, dtype=torch.float32, device=xl.device).contiguous(memory_format=torch.channels_last)
         M = B * OH * OW
-        with _lib.timed("wgrad", (M * K_out + xc.numel()) * 2 + K_out * C_in * taps * 4,
-                        f"conv {B}x{H}x{W} {C_in}->{K_out} k{KH}s{stride}", flops=2.0 * M * K_out * C_in * taps):
-            rc = lib.dfine_conv_wgrad(_lib.ptr(gyc), _lib.ptr(xc), _lib.ptr(dw), B, H, W, C_in, OH, OW, K_out, KH, KW,
-                                      stride, padding, ldy, ldx, _lib.stream_ptr())
+        with on_wgrad_stream(gyc, xc) if direct else _NullCtx():
+            with _lib.timed("wgrad", (M * K_out + xc.numel()) * 2 + K_out * C_in * taps * 4,
+                            f"conv {B}x{H}x{W} {C_in}->{K_out} k{KH}s{stride}", flops=2.0 * M * K_out * C_in * taps):
+                rc = lib.dfine_conv_wgrad(_lib.ptr(gyc), _lib.ptr(xc), _lib.ptr(dw), B, H, W, C_in, OH, OW, K_out, KH, KW,
+                                          stride, padding, ldy, ldx, _lib.stream_ptr())
         _lib.check(rc, "dfine_conv_wgrad")
         return dx, (None if direct else dw.to(weight.dtype)), None, None, None, None, None
 
