@@ -52,10 +52,13 @@ SIGNATURES = {
                             _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p] + [_c_int] * 4 + [ctypes.c_float, _c_void_p],
     "dfine_transpose_weights": [_c_void_p] * 4 + [_c_int, _c_void_p],
     "dfine_embedding_wgrad": [_c_void_p, _c_void_p, _c_int, _c_void_p, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_void_p],
+    "dfine_wgrad_group_eligible": [_c_void_p],
+    "dfine_wgrad_group_plan": [_c_void_p, _c_int, _c_void_p, ctypes.c_longlong],
+    "dfine_wgrad_group_launch": [_c_void_p, _c_void_p, _c_void_p],
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 IGEMM_MAX_TAPS = 16
@@ -68,6 +71,14 @@ class IGemmGeom(ctypes.Structure):
                                       "isy", "isx", "OHf", "OWf", "osy", "osx", "ooy", "oox", "act")] + [
         ("tap_dy", ctypes.c_byte * IGEMM_MAX_TAPS), ("tap_dx", ctypes.c_byte * IGEMM_MAX_TAPS),
         ("tap_w", ctypes.c_byte * IGEMM_MAX_TAPS)]
+
+
+class WgradProblem(ctypes.Structure):
+    """dfine_wgrad_problem of include/dfine_hip.h (one queued weight gradient of a grouped launch)."""
+
+    _fields_ = [("dY", _c_void_p), ("X", _c_void_p), ("dW", _c_void_p), ("db", _c_void_p)] + [
+        (n, _c_int) for n in ("conv", "M", "N", "K", "ldw", "B", "H", "W", "CI", "OH", "OW", "CO", "KH", "KW", "stride", "pad",
+                              "ldy", "ldx")]
 
 
 class DfineHipError(RuntimeError):
@@ -88,7 +99,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_longlong if name.endswith("_workspace") else _c_int
+        fn.restype = ctypes.c_longlong if name.endswith(("_workspace", "_plan")) else _c_int
     got = lib.dfine_abi_version()
     if got != ABI_VERSION:
         raise DfineHipError(f"libdfine_hip.so ABI {got} != expected {ABI_VERSION}: rebuild it")

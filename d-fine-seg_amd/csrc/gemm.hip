@@ -25,6 +25,10 @@
 // 128/256-byte rows those land on 2 (1) bank slots, a 4x (8x) conflict. The 32-byte chunks of a row are
 // therefore XOR-swizzled by row (swz()) so the 8 rows of a half cover the whole 256-byte bank row.
 #include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
 
 #include "common.h"
 
@@ -105,10 +109,9 @@ struct PixelCursor {
 // XVEC: widest aligned load of X: 8 = a 16-byte chunk is 8 channels of ONE tap (CI % 8 == 0) resp. 8 columns of a Linear
 // row; 4 / 1 = a chunk is assembled from 8-byte / 2-byte pieces that may belong to different taps (CI = 12, 3, 21, ...).
 template <int TN, int TK, bool CONV, int DEPTH, bool EDGE, int XVEC>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
-                                                    float* __restrict__ dW, float* __restrict__ db, int M, int N,
-                                                    int K, int ldw, int m_chunk, int n_chunks, int k_tiles,
-                                                    int tiles, ConvGeom geom) {
+__device__ __forceinline__ void wgrad_tile(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, float* __restrict__ dW,
+                                           float* __restrict__ db, int N, int K, int ldw, int m_begin, int m_end, int n0,
+                                           int k0, const ConvGeom& geom) {
   constexpr int FN = TN / 32, FK = TK / 32;        // 16x16 fragments per wave (waves tile the output 2 x 2)
   constexpr int A_ROWS = TN / 64, B_ROWS = TK / 64;  // rows each thread stages per step (16-byte chunks)
   constexpr int A_CPR = TN / 8, B_CPR = TK / 8;    // 16-byte chunks per tile row
@@ -116,16 +119,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict_
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * WG_MSTEP * (TN + TK)];
   bf16_t* const a_tile0 = lds;
   bf16_t* const b_tile0 = lds + 2 * WG_MSTEP * TN;
-
-  // XCD-aware decode: consecutive workgroup ids go round-robin to the 8 XCDs; all tiles of one m-chunk
-  // share the chunk's dY/X rows, so they are given ids of one residue class (one XCD, one L2)
-  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-  const int chunk = xcd + 8 * (slot / tiles), tile = slot % tiles;
-  if (chunk >= n_chunks) return;  // whole workgroup, before any barrier
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_n = wave >> 1, wave_k = wave & 1;
-  const int n0 = (tile / k_tiles) * TN, k0 = (tile % k_tiles) * TK;
-  const int m_begin = chunk * m_chunk, m_end = min(m_begin + m_chunk, M);
   const bool want_bias = db != nullptr && k0 == 0;
 
   // staging coordinates: thread -> (row, 16-byte chunk) per operand
@@ -299,6 +294,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict_
   }
 }
 
+// One problem per launch: workgroup -> (m-chunk, output tile).
+template <int TN, int TK, bool CONV, int DEPTH, bool EDGE, int XVEC>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X,
+                                                    float* __restrict__ dW, float* __restrict__ db, int M, int N,
+                                                    int K, int ldw, int m_chunk, int n_chunks, int k_tiles,
+                                                    int tiles, ConvGeom geom) {
+  // XCD-aware decode: consecutive workgroup ids go round-robin to the 8 XCDs; all tiles of one m-chunk
+  // share the chunk's dY/X rows, so they are given ids of one residue class (one XCD, one L2)
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int chunk = xcd + 8 * (slot / tiles), tile = slot % tiles;
+  if (chunk >= n_chunks) return;  // whole workgroup, before any barrier
+  const int m_begin = chunk * m_chunk;
+  wgrad_tile<TN, TK, CONV, DEPTH, EDGE, XVEC>(dY, X, dW, db, N, K, ldw, m_begin, min(m_begin + m_chunk, M), (tile / k_tiles) * TN,
+                                              (tile % k_tiles) * TK, geom);
+}
+
+// Many problems per launch (the deferred weight gradients of a whole backward pass): a block table built on the host maps
+// workgroup -> (problem, m-chunk, tile); see dfine_wgrad_group_plan. Entries with problem < 0 pad the XCD interleave.
+struct WgradProblem {
+  const bf16_t* dY;
+  const bf16_t* X;
+  float* dW;
+  float* db;
+  int M, N, K, ldw;
+  int m_chunk, k_tiles, variant, n_chunks;
+  ConvGeom geom;
+  int pad[2];
+};
+static_assert(sizeof(WgradProblem) == 112, "table layout");
+
+template <int TN, int TK, bool CONV>
+__global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const WgradProblem* __restrict__ problems, const int4* __restrict__ blocks) {
+  const int4 e = blocks[blockIdx.x];
+  if (e.x < 0) return;
+  const WgradProblem* p = problems + e.x;
+  const int M = p->M, m_chunk = p->m_chunk, k_tiles = p->k_tiles;
+  const ConvGeom geom = p->geom;
+  const int m_begin = e.y * m_chunk;
+  wgrad_tile<TN, TK, CONV, 4, false, 8>(p->dY, p->X, p->dW, p->db, p->N, p->K, p->ldw, m_begin, min(m_begin + m_chunk, M),
+                                        (e.z / k_tiles) * TN, (e.z % k_tiles) * TK, geom);
+}
+
 // a 128-wide tile only where it wastes no more padding than 64-wide tiles do
 static inline int tile_width(int n) { return ((n + 127) / 128 * 128 == (n + 63) / 64 * 64) ? 128 : 64; }
 
@@ -311,7 +348,9 @@ static int launch_wgrad(const void* dY, const void* X, float* dW, float* db, int
   // traffic (M*(N+K)*2 bytes); chunks of at least 256 rows; a multiple of 8 chunks (one residue class
   // per XCD). Tile shape: the largest that still fills half the capacity (128-wide tiles halve the LDS
   // and L2 reads per MFMA but a small problem needs the parallelism more).
-  long long by_traffic = ((long long)M * (N + K)) / (2LL * N * K);
+  static const int atomic_w = getenv("DFINE_WGRAD_ATOMIC_W") ? atoi(getenv("DFINE_WGRAD_ATOMIC_W")) : 2;
+  static const int fill_div = getenv("DFINE_WGRAD_FILL_DIV") ? atoi(getenv("DFINE_WGRAD_FILL_DIV")) : 2;
+  long long by_traffic = ((long long)M * (N + K)) / ((long long)atomic_w * N * K);
   if (by_traffic > (M + 255) / 256) by_traffic = (M + 255) / 256;
   if (by_traffic < 1) by_traffic = 1;
   const int want_n = tile_width(N), want_k = tile_width(K);
@@ -328,7 +367,7 @@ static int launch_wgrad(const void* dY, const void* X, float* dW, float* db, int
     if (chunks > by_traffic) chunks = by_traffic;
     if (chunks >= 8) chunks = chunks / 8 * 8;
     if (chunks < 1) chunks = 1;
-    if (tiles * chunks * 2 >= capacity) break;
+    if (tiles * chunks * fill_div >= capacity) break;
   }
   long long m_chunk = ((long long)M + chunks - 1) / chunks;
   m_chunk = (m_chunk + WG_MSTEP * DEPTH - 1) / (WG_MSTEP * DEPTH) * (WG_MSTEP * DEPTH);
@@ -348,9 +387,160 @@ static int launch_wgrad(const void* dY, const void* X, float* dW, float* db, int
   return 0;
 }
 
+// ---- grouped launch: host-side planning ------------------------------------------------------------------------------
+struct GroupLaunch {
+  int variant, grid;
+  long long blocks_off;
+};
+struct GroupHeader {
+  int magic, n_problems, n_launches, pad;
+  long long problems_off, total_bytes;
+  GroupLaunch launch[8];
+};
+constexpr int GROUP_MAGIC = 0x57475250;  // "WGRP"
+
+// public problem -> device descriptor (without the split); false: not servable by the aligned (16-byte loads) build
+static bool group_normalise(const dfine_wgrad_problem& q, WgradProblem* out) {
+  WgradProblem w{};
+  if (!q.dY || !q.X || !q.dW) return false;
+  w.dY = (const bf16_t*)q.dY, w.X = (const bf16_t*)q.X, w.dW = q.dW, w.db = q.db;
+  bool conv = false;
+  if (q.conv) {
+    if (q.B <= 0 || q.H <= 0 || q.W <= 0 || q.CI <= 0 || q.OH <= 0 || q.OW <= 0 || q.CO <= 0 || q.KH <= 0 || q.KW <= 0 ||
+        q.stride <= 0 || q.pad < 0 || q.ldy < q.CO || q.ldx < q.CI || q.db)
+      return false;
+    if ((q.OH - 1) * q.stride - q.pad >= q.H || (q.OW - 1) * q.stride - q.pad >= q.W) return false;
+    const long long M = (long long)q.B * q.OH * q.OW;
+    if (M > 0x7fffffffLL - 4096 || (long long)q.B * q.H * q.W * q.ldx > 0x7fffffffffLL) return false;
+    w.M = (int)M, w.N = q.CO, w.K = q.KH * q.KW * q.CI, w.ldw = w.K;
+    w.geom = ConvGeom{q.H, q.W, q.CI, q.OH, q.OW, q.KW, q.stride, q.pad, q.ldy, q.ldx};
+    conv = !(q.KH == 1 && q.KW == 1 && q.stride == 1 && q.pad == 0 && q.OH == q.H && q.OW == q.W);
+    if (q.CI % 8 != 0) return false;
+  } else {
+    if (q.M <= 0 || q.N <= 0 || q.K <= 0 || q.ldw < q.K || q.ldy < q.N || q.ldx < q.K || q.M > 0x7fffffff - 4096) return false;
+    w.M = q.M, w.N = q.N, w.K = q.K, w.ldw = q.ldw;
+    w.geom = ConvGeom{};
+    w.geom.ldy = q.ldy, w.geom.ldx = q.ldx;
+    if (q.K % 8 != 0) return false;
+  }
+  if (w.N % 8 != 0 || q.ldy % 8 != 0 || (uintptr_t)q.dY % 16 != 0 || q.ldx % 8 != 0 || (uintptr_t)q.X % 16 != 0) return false;
+  const int tn = tile_width(w.N), tk = tile_width(w.K);
+  w.variant = (conv ? 4 : 0) | (tn == 128 ? 2 : 0) | (tk == 128 ? 1 : 0);
+  w.k_tiles = (w.K + tk - 1) / tk;
+  *out = w;
+  return true;
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 }  // namespace dfine
 
 using namespace dfine;
+
+extern "C" int dfine_wgrad_group_eligible(const dfine_wgrad_problem* problem) {
+  WgradProblem w;
+  return problem && group_normalise(*problem, &w) ? 1 : 0;
+}
+
+extern "C" long long dfine_wgrad_group_plan(const dfine_wgrad_problem* problems, int n, void* table, long long capacity) {
+  if (!problems || n <= 0) return DFINE_E_BADARG;
+  // Split of the row axis. With hundreds of problems in one launch the grid is full whatever the split, so chunks are LONG:
+  // the fp32 atomics of a partial tile (chunks * N*K*4 bytes at ~1.3 TB/s) stay below 1/16 of the operand bytes
+  // (M*(N+K)*2 at ~5 TB/s), and a workgroup's prologue / epilogue is amortised over 32..ROWS_MAX/32 steps.
+  static const int rows_max = env_int("DFINE_WGRAD_GROUP_ROWS_MAX", 4096), rows_min = env_int("DFINE_WGRAD_GROUP_ROWS_MIN", 1024);
+  static const int atomic_w = env_int("DFINE_WGRAD_GROUP_ATOMIC_W", 32);
+  std::vector<WgradProblem> ps(n);
+  struct Group { int problem, chunk, tiles, steps; };
+  std::vector<Group> groups[8];
+  for (int i = 0; i < n; ++i) {
+    WgradProblem& w = ps[i];
+    if (!group_normalise(problems[i], &w)) return DFINE_E_UNSUPPORTED;
+    const int tn = (w.variant & 2) ? 128 : 64, tk = (w.variant & 1) ? 128 : 64;
+    const int tiles = ((w.N + tn - 1) / tn) * w.k_tiles;
+    long long chunks = ((long long)w.M * (w.N + w.K)) / ((long long)atomic_w * w.N * w.K);
+    const long long lo = ((long long)w.M + rows_max - 1) / rows_max, hi = ((long long)w.M + rows_min - 1) / rows_min;
+    if (chunks < lo) chunks = lo;
+    if (chunks > hi) chunks = hi;
+    if (chunks < 1) chunks = 1;
+    long long m_chunk = ((long long)w.M + chunks - 1) / chunks;
+    m_chunk = (m_chunk + WG_MSTEP * 4 - 1) / (WG_MSTEP * 4) * (WG_MSTEP * 4);
+    w.m_chunk = (int)m_chunk;
+    w.n_chunks = (int)(((long long)w.M + m_chunk - 1) / m_chunk);
+    for (int c = 0; c < w.n_chunks; ++c) groups[w.variant].push_back(Group{i, c, tiles, (int)(m_chunk / WG_MSTEP)});
+  }
+  // Block tables, one per kernel variant. Workgroup ids go round-robin to the 8 XCDs: the tiles of one (problem, chunk)
+  // share that chunk's dY / X rows, so they get consecutive slots of ONE XCD (one L2); groups go to the least loaded XCD,
+  // longest first.
+  GroupHeader h{};
+  h.magic = GROUP_MAGIC, h.n_problems = n;
+  h.problems_off = sizeof(GroupHeader);
+  long long off = h.problems_off + (long long)n * sizeof(WgradProblem);
+  std::vector<std::vector<int4>> tables;
+  for (int v = 0; v < 8; ++v) {
+    std::vector<Group>& g = groups[v];
+    if (g.empty()) continue;
+    std::stable_sort(g.begin(), g.end(), [](const Group& a, const Group& b) { return a.steps > b.steps; });
+    std::vector<int4> seq[8];
+    long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (const Group& gr : g) {
+      int x = 0;
+      for (int j = 1; j < 8; ++j)
+        if (load[j] < load[x]) x = j;
+      for (int t = 0; t < gr.tiles; ++t) seq[x].push_back(int4{gr.problem, gr.chunk, t, 0});
+      load[x] += (long long)gr.tiles * gr.steps;
+    }
+    size_t len = 0;
+    for (int x = 0; x < 8; ++x) len = std::max(len, seq[x].size());
+    if (len * 8 > 0x7fffffffULL) return DFINE_E_UNSUPPORTED;
+    std::vector<int4> tab(len * 8, int4{-1, 0, 0, 0});
+    for (int x = 0; x < 8; ++x)
+      for (size_t s = 0; s < seq[x].size(); ++s) tab[s * 8 + x] = seq[x][s];
+    GroupLaunch& L = h.launch[h.n_launches++];
+    L.variant = v, L.grid = (int)tab.size(), L.blocks_off = off;
+    off += (long long)tab.size() * sizeof(int4);
+    tables.push_back(std::move(tab));
+  }
+  h.total_bytes = off;
+  if (!table) return off;
+  if (capacity < off) return DFINE_E_BADARG;
+  char* out = (char*)table;
+  memcpy(out, &h, sizeof(h));
+  memcpy(out + h.problems_off, ps.data(), (size_t)n * sizeof(WgradProblem));
+  for (int l = 0; l < h.n_launches; ++l) memcpy(out + h.launch[l].blocks_off, tables[l].data(), tables[l].size() * sizeof(int4));
+  return off;
+}
+
+extern "C" int dfine_wgrad_group_launch(const void* table_host, const void* table_dev, void* stream) {
+  if (!table_host || !table_dev) return DFINE_E_BADARG;
+  const GroupHeader* h = (const GroupHeader*)table_host;
+  if (h->magic != GROUP_MAGIC || h->n_launches < 0 || h->n_launches > 8) return DFINE_E_BADARG;
+  const char* dev = (const char*)table_dev;
+  const WgradProblem* problems = (const WgradProblem*)(dev + h->problems_off);
+  hipStream_t st = (hipStream_t)stream;
+  for (int l = 0; l < h->n_launches; ++l) {
+    const GroupLaunch& L = h->launch[l];
+    const int4* blocks = (const int4*)(dev + L.blocks_off);
+#define DFINE_GROUP_LAUNCH(TN_, TK_, CONV_) \
+  hipLaunchKernelGGL((wgrad_group_kernel<TN_, TK_, CONV_>), dim3((unsigned)L.grid), dim3(256), 0, st, problems, blocks)
+    switch (L.variant) {
+      case 0: DFINE_GROUP_LAUNCH(64, 64, false); break;
+      case 1: DFINE_GROUP_LAUNCH(64, 128, false); break;
+      case 2: DFINE_GROUP_LAUNCH(128, 64, false); break;
+      case 3: DFINE_GROUP_LAUNCH(128, 128, false); break;
+      case 4: DFINE_GROUP_LAUNCH(64, 64, true); break;
+      case 5: DFINE_GROUP_LAUNCH(64, 128, true); break;
+      case 6: DFINE_GROUP_LAUNCH(128, 64, true); break;
+      case 7: DFINE_GROUP_LAUNCH(128, 128, true); break;
+      default: return DFINE_E_BADARG;
+    }
+#undef DFINE_GROUP_LAUNCH
+    DFINE_LAUNCH_CHECK();
+  }
+  return 0;
+}
 
 // `edge`: dY side (N, ldy, base) not 16-byte friendly; `xvec`: widest aligned piece of an X chunk (8, 4 or 1 elements)
 template <bool CONV>

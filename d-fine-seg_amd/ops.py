@@ -3,6 +3,7 @@ HIP kernels from libdfine_hip.so. Names and argument meaning follow the referenc
 operator seams so the parity tests read like calls into the reference.
 """
 import ctypes
+import os
 from typing import List, Sequence
 
 import torch
@@ -813,9 +814,118 @@ class on_wgrad_stream:
 
 
 def join_wgrad():
-    """The current stream waits for every weight-gradient launch forked so far."""
+    """Launch the queued (deferred) weight gradients; the current stream waits for every weight-gradient launch forked to the
+    side stream. After this the fp32 gradients of every layer whose backward has run are complete (in stream order)."""
+    if wgrad_queue is not None:
+        wgrad_queue.flush()
     if wgrad_stream is not None:
         torch.cuda.current_stream().wait_stream(wgrad_stream)
+
+
+class WgradQueue:
+    """Deferred, grouped weight gradients (include/dfine_hip.h: dfine_wgrad_group_*). While a queue is installed
+    (``ops.wgrad_queue``; ``TrainStep`` does) the backward of every Linear / dense Conv2d that accumulates straight into the
+    flat fp32 gradient only RECORDS its problem -- (dY, X) stay alive, which costs a few GB of the 288 -- and ``flush()``
+    launches them all at once: the ~190 weight gradients of a D-FINE-m step, most of which cannot fill 256 CUs on their own and
+    pay a partial-tile atomic tail each, become one full-chip launch per tile shape with long row chunks. Problems the aligned
+    kernel cannot serve (the 3-channel stem, N % 8 != 0 heads) are launched on the spot by the caller as before.
+
+    Under hipGraph capture the launch table lives in PERSISTENT device memory reserved before the capture (``reserve``) and
+    is uploaded after it (``upload_pending``): a captured launch only records pointers. The table must not come from the
+    graph's own memory pool -- a block allocated late in a capture is one that earlier kernels of the same graph used and
+    freed, and every replay would run those kernels over the table before the grouped launch reads it."""
+
+    def __init__(self):
+        self.problems, self.keep = [], []
+        self.bytes = self.flops = 0
+        self.pending_uploads = []
+        self.table_chunks, self.table_off = [], 0  # persistent memory for the tables of captured launches
+        self.max_need = 0
+        self.launches = self.single_fallbacks = 0
+
+    def reserve(self, device):
+        """Outside any capture: make room for the tables of the next captured step (a few launches of the largest table seen)."""
+        want = max(4 << 20, 4 * self.max_need)
+        if not self.table_chunks or self.table_chunks[-1].numel() - self.table_off < want:
+            self.table_chunks.append(torch.empty(want, dtype=torch.uint8, device=device))
+            self.table_off = 0
+
+    def _persistent(self, need):
+        if not self.table_chunks or self.table_chunks[-1].numel() - self.table_off < need:
+            return None
+        view = self.table_chunks[-1][self.table_off : self.table_off + need]
+        self.table_off += (need + 255) // 256 * 256
+        return view
+
+    def _launch_singly(self):
+        lib = _lib.load()
+        for q in self.problems:
+            if q.conv:
+                rc = lib.dfine_conv_wgrad(q.dY, q.X, q.dW, q.B, q.H, q.W, q.CI, q.OH, q.OW, q.CO, q.KH, q.KW, q.stride, q.pad, q.ldy, q.ldx,
+                                          _lib.stream_ptr())
+            else:
+                rc = lib.dfine_linear_wgrad(q.dY, q.X, q.dW, q.db, q.M, q.N, q.K, q.ldw, q.ldy, q.ldx, _lib.stream_ptr())
+            _lib.check(rc, "queued wgrad")
+        self.single_fallbacks += 1
+        self.discard()
+
+    def add(self, problem, keep, nbytes, flops):
+        """Queue ``problem`` (a _lib.WgradProblem) if the grouped kernel can serve it; False: launch it yourself."""
+        lib = _lib.load()
+        if not lib.dfine_wgrad_group_eligible(ctypes.byref(problem)):
+            return False
+        self.problems.append(problem)
+        self.keep.append(keep)
+        self.bytes += nbytes
+        self.flops += flops
+        return True
+
+    def flush(self):
+        n = len(self.problems)
+        if n == 0:
+            return
+        lib = _lib.load()
+        if os.environ.get("DFINE_WGRAD_QUEUE_SINGLE") == "1":  # diagnostic: deferred, but one launch per problem
+            return self._launch_singly()
+        arr = (_lib.WgradProblem * n)(*self.problems)
+        need = lib.dfine_wgrad_group_plan(arr, n, None, 0)
+        if need <= 0:
+            _lib.check(int(need) if need < 0 else -1, "dfine_wgrad_group_plan")
+        device = self.keep[0][0].device
+        capturing = torch.cuda.is_current_stream_capturing()
+        host = torch.empty(int(need), dtype=torch.uint8, pin_memory=not capturing)
+        used = lib.dfine_wgrad_group_plan(arr, n, ctypes.c_void_p(host.data_ptr()), int(need))
+        if used != need:
+            _lib.check(int(used) if used < 0 else -1, "dfine_wgrad_group_plan")
+        self.max_need = max(self.max_need, int(need))
+        if capturing:
+            dev = self._persistent(int(need))
+            if dev is None:  # nobody reserved table memory before this capture: correct, just not grouped
+                return self._launch_singly()
+            self.pending_uploads.append((dev, host))
+        else:
+            dev = torch.empty(int(need), dtype=torch.uint8, device=device)
+            dev.copy_(host, non_blocking=True)
+        with _lib.timed("wgrad", self.bytes, f"grouped x{n}", flops=self.flops):
+            rc = lib.dfine_wgrad_group_launch(ctypes.c_void_p(host.data_ptr()), _lib.ptr(dev), _lib.stream_ptr())
+        _lib.check(rc, "dfine_wgrad_group_launch")
+        self.launches += 1
+        self.problems, self.keep = [], []
+        self.bytes = self.flops = 0
+
+    def upload_pending(self):
+        """After a capture ended: fill the device tables its grouped launches will read on replay."""
+        for dev, host in self.pending_uploads:
+            dev.copy_(host)
+        self.pending_uploads = []
+
+    def discard(self):
+        """Drop queued problems without launching (a failed / abandoned backward)."""
+        self.problems, self.keep = [], []
+        self.bytes = self.flops = 0
+
+
+wgrad_queue = None
 
 
 # Accumulate Linear weight gradients straight into ``param.grad`` (the flat fp32 gradient buffer) and
@@ -899,8 +1009,14 @@ class _Linear(torch.autograd.Function):
         else:
             dw = torch.zeros(N, K, dtype=torch.float32, device=x2.device)
             db = torch.zeros(N, dtype=torch.float32, device=x2.device) if bias is not None else None
+        nbytes, flops = (M * N + M * K) * 2 + N * K * 4, 2.0 * M * N * K
+        if direct and wgrad_queue is not None:
+            prob = _lib.WgradProblem(dY=gy16.data_ptr(), X=x2.data_ptr(), dW=dw.data_ptr(), db=db.data_ptr() if db is not None else None,
+                                     conv=0, M=M, N=N, K=K, ldw=K, ldy=N, ldx=K)
+            if wgrad_queue.add(prob, (gy16, x2), nbytes, flops):
+                return dx, None, None, None, None, None
         with on_wgrad_stream(gy16, x2 if direct else None) if direct else _NullCtx():
-            with _lib.timed("wgrad", (M * N + M * K) * 2 + N * K * 4, f"linear M{M} N{N} K{K}", flops=2.0 * M * N * K):
+            with _lib.timed("wgrad", nbytes, f"linear M{M} N{N} K{K}", flops=flops):
                 rc = lib.dfine_linear_wgrad(_lib.ptr(gy16), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), M, N, K, K, N, K, _lib.stream_ptr())
         _lib.check(rc, "dfine_linear_wgrad")
         if direct:
@@ -986,9 +1102,15 @@ class _DenseConv(torch.autograd.Function):
         else:
             dw = torch.zeros(K_out, C_in, KH, KW, dtype=torch.float32, device=xl.device).contiguous(memory_format=torch.channels_last)
         M = B * OH * OW
+        nbytes, flops = (M * K_out + xc.numel()) * 2 + K_out * C_in * taps * 4, 2.0 * M * K_out * C_in * taps
+        if direct and wgrad_queue is not None:
+            prob = _lib.WgradProblem(dY=gyc.data_ptr(), X=xc.data_ptr(), dW=dw.data_ptr(), db=None, conv=1, B=B, H=H, W=W, CI=C_in,
+                                     OH=OH, OW=OW, CO=K_out, KH=KH, KW=KW, stride=stride, pad=padding, ldy=ldy, ldx=ldx)
+            if wgrad_queue.add(prob, (gyc, xc), nbytes, flops):
+                return dx, None, None, None, None, None, None
         with on_wgrad_stream(gyc, xc) if direct else _NullCtx():
-            with _lib.timed("wgrad", (M * K_out + xc.numel()) * 2 + K_out * C_in * taps * 4,
-                            f"conv {B}x{H}x{W} {C_in}->{K_out} k{KH}s{stride}", flops=2.0 * M * K_out * C_in * taps):
+            with _lib.timed("wgrad", nbytes,
+                            f"conv {B}x{H}x{W} {C_in}->{K_out} k{KH}s{stride}", flops=flops):
                 rc = lib.dfine_conv_wgrad(_lib.ptr(gyc), _lib.ptr(xc), _lib.ptr(dw), B, H, W, C_in, OH, OW, K_out, KH, KW,
                                           stride, padding, ldy, ldx, _lib.stream_ptr())
         _lib.check(rc, "dfine_conv_wgrad")

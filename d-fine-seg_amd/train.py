@@ -99,7 +99,7 @@ class TrainStep:
     def __init__(self, model_name="m", num_classes=80, enable_mask_head=False, img_size=(640, 640),
                  device="cuda", base_lr=1.5e-4, backbone_lr=2e-5, betas=(0.9, 0.999), weight_decay=1.25e-4,
                  clip_max_norm=0.1, use_ema=True, ema_momentum=0.9998, amp=True, total_steps=10000,
-                 pct_start=0.1, grad_reducer=None, use_graph=True, graph_warmup=3, graph_masks=True, overlap_wgrad=False):
+                 pct_start=0.1, grad_reducer=None, use_graph=True, graph_warmup=3, graph_masks=True, overlap_wgrad=False, defer_wgrad=True):
         self.device = torch.device(device)
         self.num_classes = num_classes
         self.model = build_model(model_name, num_classes, enable_mask_head, self.device, img_size=list(img_size))
@@ -141,6 +141,12 @@ class TrainStep:
         # D-FINE-m batch 32: 45.96 ms/step with the fork/join edges in the graph vs 44.6 without -- the two branches compete
         # for HBM and the graph's parallel-branch bookkeeping costs more than the overlapped tails give; off by default
         self.wgrad_stream = torch.cuda.Stream(self.device) if (self.device.type == "cuda" and overlap_wgrad) else None
+        # weight gradients are queued during backward and launched grouped at its end (ops.WgradQueue): on by default
+        self.wgrad_queue = None
+        if self.device.type == "cuda" and defer_wgrad and not overlap_wgrad:
+            from . import ops
+
+            self.wgrad_queue = ops.WgradQueue()
         self._graph_pool = None   # every captured graph of this step shares one private memory pool
         self.max_graphs = 16      # bounded: each distinct (shape, GT count) key is one graph
         self.last_step_replayed = False  # whether the most recent step() replayed a captured graph
@@ -170,6 +176,9 @@ class TrainStep:
 
         ops.zero_arena = self.arena  # this step's scratch (module-level handle: the ops are free functions)
         ops.wgrad_stream = self.wgrad_stream
+        ops.wgrad_queue = self.wgrad_queue
+        if self.wgrad_queue is not None:
+            self.wgrad_queue.discard()  # leftovers of an abandoned backward must never reach this step's launch
         if self.arena is not None:
             self.arena.reset()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
@@ -214,6 +223,10 @@ class TrainStep:
         return self._loss_backward(out, state)
 
     def _optimizer_tail(self):
+        from . import ops
+
+        ops.join_wgrad()  # every backward piece flushed already: nothing may be left in the queue
+        ops.wgrad_queue = None  # the step's backward is over: ops used outside this step launch their own weight gradients
         self.optimizer.launch()  # clip + AdamW + EMA(params) + bf16 shadow + zero grads
         if self.ema is not None:
             self.ema.update_buffers(self.optimizer.hyper[6])
@@ -300,7 +313,12 @@ class TrainStep:
         was_enabled = gc.isenabled()
         gc.disable()
         try:
-            return self._capture_impl(images, tb, inject)
+            if self.wgrad_queue is not None:
+                self.wgrad_queue.reserve(self.device)  # persistent memory for the launch tables: not the graph's pool
+            captured = self._capture_impl(images, tb, inject)
+            if self.wgrad_queue is not None:
+                self.wgrad_queue.upload_pending()  # the launch tables the captured grouped wgrad launches read on replay
+            return captured
         finally:
             if was_enabled:
                 gc.enable()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 2
+#define DFINE_ABI_VERSION 3
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -238,6 +238,35 @@ int dfine_linear_wgrad(const void* dY, const void* X, float* dW, float* db, int 
  * ------------------------------------------------------------------------------------- */
 int dfine_conv_wgrad(const void* dY, const void* X, float* dW, int B, int H, int W, int CI, int OH, int OW,
                      int CO, int KH, int KW, int stride, int pad, int ldy, int ldx, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * The same weight gradients, DEFERRED and GROUPED: a backward pass queues one `dfine_wgrad_problem` per Linear / Conv2d
+ * (the operands stay alive -- 288 GB of HBM make that cheap) and launches them together when the pass, or one stage of
+ * it, is done. One launch per tile shape covers every problem: the grid is full whatever the size of a single problem
+ * (the 20x20 / 40x40 maps and the 15 744-token decoder GEMMs do not fill 256 CUs on their own), each problem's row axis
+ * is split into few long chunks (few float atomics), and ~190 launches with their tails become <= 8.
+ *   problem: `conv` = 0 -> dfine_linear_wgrad's arguments (M, N, K, ldw, ldy, ldx, db optional);
+ *            `conv` = 1 -> dfine_conv_wgrad's (B, H, W, CI, OH, OW, CO, KH, KW, stride, pad, ldy, ldx; db must be NULL).
+ *   Only 16-byte friendly problems (N, K resp. CI, ldy, ldx multiples of 8; dY, X 16-byte aligned) can be grouped --
+ *   dfine_wgrad_group_eligible() says which; the others go through the single-problem entry points.
+ *   dfine_wgrad_group_plan (host only, no GPU call): writes the launch table for `n` problems into `table` (host memory,
+ *   `capacity` bytes) and returns the bytes used (table == NULL: the bytes needed); < 0 on error. The caller copies
+ *   those bytes to device memory (before the launch EXECUTES: under hipGraph capture that may be after the capture) and
+ *   passes both copies to dfine_wgrad_group_launch, which reads the launch list from the host copy.
+ * ------------------------------------------------------------------------------------- */
+typedef struct dfine_wgrad_problem {
+  const void* dY;
+  const void* X;
+  float* dW;
+  float* db;
+  int conv;
+  int M, N, K, ldw;                                      /* conv = 0 */
+  int B, H, W, CI, OH, OW, CO, KH, KW, stride, pad;      /* conv = 1 */
+  int ldy, ldx;
+} dfine_wgrad_problem;
+int dfine_wgrad_group_eligible(const dfine_wgrad_problem* problem);
+long long dfine_wgrad_group_plan(const dfine_wgrad_problem* problems, int n, void* table, long long capacity);
+int dfine_wgrad_group_launch(const void* table_host, const void* table_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * FDR head of one decoder layer (reference src/d_fine/arch/dfine_decoder.py:276-296 Integral,
