@@ -163,28 +163,33 @@ def test_captured_bf16_step_equals_eager_step_from_the_same_state(hip_lib, task)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("amp", [False])
-def test_graph_replay_matches_eager(hip_lib, amp):
-    """The captured step must compute what the eager step computes (same weights, same batches); with ``amp`` the
-    benchmarked path (bf16 shadow weights, implicit-GEMM / wgrad kernels, direct accumulation) is what is replayed.
-    Tolerance: fp32 2e-3 (atomic summation order), bf16 2e-2."""
+def test_graph_replay_matches_eager(hip_lib):
+    """fp32 (no autocast): every replayed step must compute what the eager step computes FROM THE SAME STATE -- compared step
+    by step (six batches through one graph), not as two free-running trajectories: those drift apart chaotically once a
+    single Hungarian assignment flips on the order of float atomics (observed: five steps equal to 1e-5, the sixth 1 % off).
+    Loss within 2e-3, updated weights within 1e-3 relative L2."""
     from dfine_seg_amd.synth import synthetic_batch
     from dfine_seg_amd.train import TrainStep
 
-    losses = {}
-    for use_graph in (False, True):
-        torch.manual_seed(0)
-        t = TrainStep("n", 80, False, (320, 320), "cuda", total_steps=100, use_graph=use_graph, graph_warmup=2, amp=amp)
-        out = []
-        for i in range(6):
-            torch.manual_seed(100 + i)  # same denoising noise stream for both runs
-            images, targets = synthetic_batch(2, 320, 320, 80, 4, seed=i, device="cuda")
-            out.append(float(t.step(images, targets)))
-        losses[use_graph] = out
-        assert (len(t._graphs) == 1) == use_graph
-    tol = 2e-2 if amp else 2e-3
-    for a, b in zip(losses[False], losses[True]):
-        assert abs(a - b) <= tol * abs(a), (losses[False], losses[True])
+    torch.manual_seed(0)
+    t = TrainStep("n", 80, False, (320, 320), "cuda", total_steps=100, use_graph=True, graph_warmup=1, amp=False)
+    t.step(*synthetic_batch(2, 320, 320, 80, 4, seed=99, device="cuda"))  # the eager warm-up step
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    for i in range(6):
+        batch = synthetic_batch(2, 320, 320, 80, 4, seed=i, device="cuda")
+        snap = _snapshot(t)
+        t.use_graph = False
+        torch.manual_seed(100 + i)
+        eager = float(t.step(*batch))
+        eager_params = t.flat.params.clone()
+        _restore(t, snap)
+        t.use_graph = True
+        torch.manual_seed(100 + i)
+        replayed = float(t.step(*batch))
+        assert t.last_step_replayed
+        assert abs(eager - replayed) <= 2e-3 * abs(eager), (i, eager, replayed)
+        assert rel(t.flat.params, eager_params) < 1e-3, (i, rel(t.flat.params, eager_params))
+    assert len(t._graphs) == 1
 
 
 @pytest.mark.gpu
