@@ -324,7 +324,7 @@ struct WgradProblem {
 };
 static_assert(sizeof(WgradProblem) == 112, "table layout");
 
-template <int TN, int TK, bool CONV>
+template <int TN, int TK, bool CONV, bool NARROW = false>
 __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const WgradProblem* __restrict__ problems, const int4* __restrict__ blocks) {
   const int4 e = blocks[blockIdx.x];
   if (e.x < 0) return;
@@ -332,8 +332,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(const WgradProblem*
   const int M = p->M, m_chunk = p->m_chunk, k_tiles = p->k_tiles;
   const ConvGeom geom = p->geom;
   const int m_begin = e.y * m_chunk;
-  wgrad_tile<TN, TK, CONV, 4, false, 8>(p->dY, p->X, p->dW, p->db, p->N, p->K, p->ldw, m_begin, min(m_begin + m_chunk, M),
-                                        (e.z / k_tiles) * TN, (e.z % k_tiles) * TK, geom);
+  wgrad_tile<TN, TK, CONV, 4, NARROW, NARROW ? 1 : 8>(p->dY, p->X, p->dW, p->db, p->N, p->K, p->ldw, m_begin, min(m_begin + m_chunk, M),
+                                                      (e.z / k_tiles) * TN, (e.z % k_tiles) * TK, geom);
 }
 
 // a 128-wide tile only where it wastes no more padding than 64-wide tiles do
@@ -388,6 +388,9 @@ static int launch_wgrad(const void* dY, const void* X, float* dW, float* db, int
 }
 
 // ---- grouped launch: host-side planning ------------------------------------------------------------------------------
+// kernel variants of a grouped launch: bit 0 TK = 128, bit 1 TN = 128, bit 2 gathered conv rows; 8 = Linear problems that are
+// not 16-byte friendly (N or K not a multiple of 8, odd pitches: the 4- / 132-wide heads), 64 x 64 tiles with narrow loads
+constexpr int GROUP_VARIANTS = 9, GROUP_NARROW = 8;
 struct GroupLaunch {
   int variant, grid;
   long long blocks_off;
@@ -395,7 +398,7 @@ struct GroupLaunch {
 struct GroupHeader {
   int magic, n_problems, n_launches, pad;
   long long problems_off, total_bytes;
-  GroupLaunch launch[8];
+  GroupLaunch launch[GROUP_VARIANTS];
 };
 constexpr int GROUP_MAGIC = 0x57475250;  // "WGRP"
 
@@ -415,17 +418,18 @@ static bool group_normalise(const dfine_wgrad_problem& q, WgradProblem* out) {
     w.M = (int)M, w.N = q.CO, w.K = q.KH * q.KW * q.CI, w.ldw = w.K;
     w.geom = ConvGeom{q.H, q.W, q.CI, q.OH, q.OW, q.KW, q.stride, q.pad, q.ldy, q.ldx};
     conv = !(q.KH == 1 && q.KW == 1 && q.stride == 1 && q.pad == 0 && q.OH == q.H && q.OW == q.W);
-    if (q.CI % 8 != 0) return false;
   } else {
     if (q.M <= 0 || q.N <= 0 || q.K <= 0 || q.ldw < q.K || q.ldy < q.N || q.ldx < q.K || q.M > 0x7fffffff - 4096) return false;
     w.M = q.M, w.N = q.N, w.K = q.K, w.ldw = q.ldw;
     w.geom = ConvGeom{};
     w.geom.ldy = q.ldy, w.geom.ldx = q.ldx;
-    if (q.K % 8 != 0) return false;
   }
-  if (w.N % 8 != 0 || q.ldy % 8 != 0 || (uintptr_t)q.dY % 16 != 0 || q.ldx % 8 != 0 || (uintptr_t)q.X % 16 != 0) return false;
-  const int tn = tile_width(w.N), tk = tile_width(w.K);
-  w.variant = (conv ? 4 : 0) | (tn == 128 ? 2 : 0) | (tk == 128 ? 1 : 0);
+  const bool wide = w.N % 8 == 0 && q.ldy % 8 == 0 && (uintptr_t)q.dY % 16 == 0 && q.ldx % 8 == 0 && (uintptr_t)q.X % 16 == 0 &&
+                    (q.conv ? q.CI % 8 == 0 : q.K % 8 == 0);
+  if (!wide && conv) return false;  // gathered rows with narrow loads (the 3-channel stem): single-problem launches only
+  if (!wide && ((uintptr_t)q.dY % 2 != 0 || (uintptr_t)q.X % 2 != 0)) return false;
+  const int tn = wide ? tile_width(w.N) : 64, tk = wide ? tile_width(w.K) : 64;
+  w.variant = wide ? ((conv ? 4 : 0) | (tn == 128 ? 2 : 0) | (tk == 128 ? 1 : 0)) : GROUP_NARROW;
   w.k_tiles = (w.K + tk - 1) / tk;
   *out = w;
   return true;
@@ -454,11 +458,11 @@ extern "C" long long dfine_wgrad_group_plan(const dfine_wgrad_problem* problems,
   static const int atomic_w = env_int("DFINE_WGRAD_GROUP_ATOMIC_W", 32);
   std::vector<WgradProblem> ps(n);
   struct Group { int problem, chunk, tiles, steps; };
-  std::vector<Group> groups[8];
+  std::vector<Group> groups[GROUP_VARIANTS];
   for (int i = 0; i < n; ++i) {
     WgradProblem& w = ps[i];
     if (!group_normalise(problems[i], &w)) return DFINE_E_UNSUPPORTED;
-    const int tn = (w.variant & 2) ? 128 : 64, tk = (w.variant & 1) ? 128 : 64;
+    const int tn = (w.variant != GROUP_NARROW && (w.variant & 2)) ? 128 : 64, tk = (w.variant != GROUP_NARROW && (w.variant & 1)) ? 128 : 64;
     const int tiles = ((w.N + tn - 1) / tn) * w.k_tiles;
     long long chunks = ((long long)w.M * (w.N + w.K)) / ((long long)atomic_w * w.N * w.K);
     const long long lo = ((long long)w.M + rows_max - 1) / rows_max, hi = ((long long)w.M + rows_min - 1) / rows_min;
@@ -479,7 +483,7 @@ extern "C" long long dfine_wgrad_group_plan(const dfine_wgrad_problem* problems,
   h.problems_off = sizeof(GroupHeader);
   long long off = h.problems_off + (long long)n * sizeof(WgradProblem);
   std::vector<std::vector<int4>> tables;
-  for (int v = 0; v < 8; ++v) {
+  for (int v = 0; v < GROUP_VARIANTS; ++v) {
     std::vector<Group>& g = groups[v];
     if (g.empty()) continue;
     std::stable_sort(g.begin(), g.end(), [](const Group& a, const Group& b) { return a.steps > b.steps; });
@@ -516,7 +520,7 @@ extern "C" long long dfine_wgrad_group_plan(const dfine_wgrad_problem* problems,
 extern "C" int dfine_wgrad_group_launch(const void* table_host, const void* table_dev, void* stream) {
   if (!table_host || !table_dev) return DFINE_E_BADARG;
   const GroupHeader* h = (const GroupHeader*)table_host;
-  if (h->magic != GROUP_MAGIC || h->n_launches < 0 || h->n_launches > 8) return DFINE_E_BADARG;
+  if (h->magic != GROUP_MAGIC || h->n_launches < 0 || h->n_launches > GROUP_VARIANTS) return DFINE_E_BADARG;
   const char* dev = (const char*)table_dev;
   const WgradProblem* problems = (const WgradProblem*)(dev + h->problems_off);
   hipStream_t st = (hipStream_t)stream;
@@ -534,6 +538,9 @@ extern "C" int dfine_wgrad_group_launch(const void* table_host, const void* tabl
       case 5: DFINE_GROUP_LAUNCH(64, 128, true); break;
       case 6: DFINE_GROUP_LAUNCH(128, 64, true); break;
       case 7: DFINE_GROUP_LAUNCH(128, 128, true); break;
+      case GROUP_NARROW:
+        hipLaunchKernelGGL((wgrad_group_kernel<64, 64, false, true>), dim3((unsigned)L.grid), dim3(256), 0, st, problems, blocks);
+        break;
       default: return DFINE_E_BADARG;
     }
 #undef DFINE_GROUP_LAUNCH

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
 }
 
 // Backward pass 1: per channel sum(dz), sum(dz * xhat), sum(dy * act(z)) [-> d lab_scale], sum(dy) [-> d lab_bias]
-template <typename T, int VEC>
+template <typename T, int VEC, int UNROLL>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const T* __restrict__ x, const T* __restrict__ addend, const T* __restrict__ dy,
     const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
@@ -225,11 +225,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[q][i] = 0.f;
   const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
-  for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL_BWD) {
-    PackedVec<T, VEC> px[DFINE_NA_UNROLL_BWD], pa[DFINE_NA_UNROLL_BWD], pd[DFINE_NA_UNROLL_BWD];
-    bool ok[DFINE_NA_UNROLL_BWD];
+  for (int n = 0; n < g.pix_per_thread; n += UNROLL) {
+    PackedVec<T, VEC> px[UNROLL], pa[UNROLL], pd[UNROLL];
+    bool ok[UNROLL];
 #pragma unroll
-    for (int u = 0; u < DFINE_NA_UNROLL_BWD; ++u) {
+    for (int u = 0; u < UNROLL; ++u) {
       const int pix = first + (n + u) * blockDim.y;
       ok[u] = n + u < g.pix_per_thread && pix < g.n_pix;
       if (ok[u]) {
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
       }
     }
 #pragma unroll
-    for (int u = 0; u < DFINE_NA_UNROLL_BWD; ++u) {
+    for (int u = 0; u < UNROLL; ++u) {
       if (!ok[u]) continue;
       float v[VEC], a[VEC], d[VEC];
       px[u].unpack(v);
@@ -428,8 +428,13 @@ static int bwd_impl(const void* x, const void* addend, const void* dy, const flo
   NaGeom g = make_geom(n_pix, C, R.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, 0.f);
   if (phase != 2) {
     const size_t lds = (size_t)R.block.y * 4 * R.block.x * VEC * sizeof(float);
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy,
-                       save_mean, save_rstd, gamma, beta, lab_scale, red, g);
+    static const int unroll = getenv("DFINE_BN_BWD_UNROLL") ? atoi(getenv("DFINE_BN_BWD_UNROLL")) : 2;
+    if (unroll == 4)
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, 4>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy,
+                         save_mean, save_rstd, gamma, beta, lab_scale, red, g);
+    else
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, 2>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy,
+                         save_mean, save_rstd, gamma, beta, lab_scale, red, g);
     DFINE_LAUNCH_CHECK();
   }
   if (phase == 1) return 0;

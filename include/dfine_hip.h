@@ -242,13 +242,15 @@ int dfine_conv_wgrad(const void* dY, const void* X, float* dW, int B, int H, int
 /* ---------------------------------------------------------------------------------------
  * The same weight gradients, DEFERRED and GROUPED: a backward pass queues one `dfine_wgrad_problem` per Linear / Conv2d
  * (the operands stay alive -- 288 GB of HBM make that cheap) and launches them together when the pass, or one stage of
- * it, is done. One launch per tile shape covers every problem: the grid is full whatever the size of a single problem
+ * it, is done. One launch per tile shape (<= 9) covers every problem: the grid is full whatever the size of a single problem
  * (the 20x20 / 40x40 maps and the 15 744-token decoder GEMMs do not fill 256 CUs on their own), each problem's row axis
- * is split into few long chunks (few float atomics), and ~190 launches with their tails become <= 8.
+ * is split into few long chunks (few float atomics), and ~190 launches with their tails become a handful.
  *   problem: `conv` = 0 -> dfine_linear_wgrad's arguments (M, N, K, ldw, ldy, ldx, db optional);
  *            `conv` = 1 -> dfine_conv_wgrad's (B, H, W, CI, OH, OW, CO, KH, KW, stride, pad, ldy, ldx; db must be NULL).
- *   Only 16-byte friendly problems (N, K resp. CI, ldy, ldx multiples of 8; dY, X 16-byte aligned) can be grouped --
- *   dfine_wgrad_group_eligible() says which; the others go through the single-problem entry points.
+ *   16-byte friendly problems (N, K resp. CI, ldy, ldx multiples of 8; dY, X 16-byte aligned) run on the wide-load tile
+ *   variants, other Linear problems (the 4- / 132-wide heads, K = 20) on a narrow-load variant; gathered convolutions that
+ *   are not 16-byte friendly (the 3-channel stem) cannot be grouped -- dfine_wgrad_group_eligible() says which, those go
+ *   through the single-problem entry points.
  *   dfine_wgrad_group_plan (host only, no GPU call): writes the launch table for `n` problems into `table` (host memory,
  *   `capacity` bytes) and returns the bytes used (table == NULL: the bytes needed); < 0 on error. The caller copies
  *   those bytes to device memory (before the launch EXECUTES: under hipGraph capture that may be after the capture) and

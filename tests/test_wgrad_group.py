@@ -63,7 +63,7 @@ def test_plan_covers_every_tile_of_every_chunk_exactly_once(hip_lib):
     assert len(parsed) == len(problems)
     seen = {}
     for variant, blocks in launches:
-        tn, tk = (128 if variant & 2 else 64), (128 if variant & 1 else 64)
+        tn, tk = (128 if variant & 2 and variant < 8 else 64), (128 if variant & 1 and variant < 8 else 64)
         assert len(blocks) % 8 == 0
         for bid, (p, chunk, tile, _) in enumerate(blocks):
             if p < 0:
@@ -75,7 +75,7 @@ def test_plan_covers_every_tile_of_every_chunk_exactly_once(hip_lib):
             assert (p, chunk, tile) not in seen
             seen[(p, chunk, tile)] = bid % 8
     for p, (M, N, K, m_chunk, k_tiles, variant, n_chunks) in enumerate(parsed):
-        tn, tk = (128 if variant & 2 else 64), (128 if variant & 1 else 64)
+        tn, tk = (128 if variant & 2 and variant < 8 else 64), (128 if variant & 1 and variant < 8 else 64)
         tiles = -(-N // tn) * -(-K // tk)
         assert m_chunk % 128 == 0 and (n_chunks - 1) * m_chunk < M <= n_chunks * m_chunk
         for c in range(n_chunks):
@@ -91,12 +91,20 @@ def test_ineligible_problems_are_refused(hip_lib):
     A = 1 << 20
     ok = _problem(_lib, 0, dY=A, X=A, dW=A, db=None, M=64, N=64, K=64, ldw=64, ldy=64, ldx=64)
     assert hip_lib.dfine_wgrad_group_eligible(ctypes.byref(ok)) == 1
+    # Linear problems that are not 16-byte friendly are served by the narrow-load variant (the 132- / 4-wide heads, K = 20)
+    for narrow in (
+        _problem(_lib, 0, dY=A, X=A, dW=A, db=None, M=64, N=132, K=64, ldw=64, ldy=132, ldx=64),
+        _problem(_lib, 0, dY=A + 2, X=A, dW=A, db=None, M=64, N=64, K=64, ldw=64, ldy=64, ldx=64),
+        _problem(_lib, 0, dY=A, X=A, dW=A, db=A, M=64, N=64, K=20, ldw=20, ldy=64, ldx=20),
+    ):
+        assert hip_lib.dfine_wgrad_group_eligible(ctypes.byref(narrow)) == 1
+        parsed, launches = _parse(_plan(hip_lib, _lib, [ok, narrow]))
+        assert parsed[1][5] == 8 and {v for v, _ in launches} == {0, 8}
     for bad in (
-        _problem(_lib, 0, dY=A, X=A, dW=A, db=None, M=64, N=132, K=64, ldw=64, ldy=132, ldx=64),   # N % 8
-        _problem(_lib, 0, dY=A + 2, X=A, dW=A, db=None, M=64, N=64, K=64, ldw=64, ldy=64, ldx=64),  # misaligned dY
-        _problem(_lib, 0, dY=A, X=A, dW=A, db=None, M=64, N=64, K=20, ldw=20, ldy=64, ldx=20),      # K % 8
+        _problem(_lib, 0, dY=A + 1, X=A, dW=A, db=None, M=64, N=64, K=64, ldw=64, ldy=64, ldx=64),  # not even bf16-aligned
         _problem(_lib, 1, dY=A, X=A, dW=A, db=None, B=2, H=8, W=8, CI=3, OH=4, OW=4, CO=24, KH=3, KW=3, stride=2, pad=1, ldy=24, ldx=3),
         _problem(_lib, 0, dY=A, X=A, dW=None, db=None, M=64, N=64, K=64, ldw=64, ldy=64, ldx=64),
+        _problem(_lib, 0, dY=A, X=A, dW=A, db=None, M=64, N=64, K=64, ldw=32, ldy=64, ldx=64),      # ldw < K
     ):
         assert hip_lib.dfine_wgrad_group_eligible(ctypes.byref(bad)) == 0
         arr = (_lib.WgradProblem * 2)(ok, bad)
@@ -151,6 +159,9 @@ def test_grouped_launch_equals_single_launches_and_fp32_reference(hip_lib):
     lin(777, 1024, 64, True)          # ragged M (not a multiple of the 32-row step)
     lin(5000, 64, 1024, False, pitch=8)  # channel slices of wider rows
     lin(40, 24, 48, False)             # a single short chunk
+    lin(3000, 132, 256, True)          # narrow-load variant: N % 8 != 0
+    lin(900, 4, 256, True)
+    lin(900, 64, 20, False)            # K % 8 != 0
     conv(4, 40, 128, 128, 3, 1, 1)
     conv(4, 40, 64, 96, 3, 2, 1)
     conv(4, 20, 384, 768, 1, 1, 0)
