@@ -39,8 +39,8 @@ class LightConv(nn.Module):
         self.conv1 = ConvNorm(c_in, c_out, 1, **{**kw, "act": None})
         self.conv2 = ConvNorm(c_out, c_out, k, groups=c_out, **kw)
 
-    def forward(self, x):
-        return self.conv2(self.conv1(x))
+    def forward(self, x, into=None):
+        return self.conv2(self.conv1(x), into=into)
 
 
 class Block(nn.Module):
@@ -49,14 +49,28 @@ class Block(nn.Module):
         make = (lambda ci: LightConv(ci, c_mid, k, kw)) if light else (lambda ci: ConvNorm(ci, c_mid, k, **kw))
         self.layers = nn.ModuleList(make(c_in if i == 0 else c_mid) for i in range(n_layers))
         total = c_in + n_layers * c_mid
+        self.part_channels = [c_in] + [c_mid] * n_layers
         self.aggregation = nn.Sequential(ConvNorm(total, c_out // 2, 1, **kw), ConvNorm(c_out // 2, c_out, 1, **kw))
         self.residual = residual
 
     def forward(self, x):
-        feats = [x]
-        for layer in self.layers:
-            feats.append(layer(feats[-1]))
-        y = self.aggregation(torch.cat(feats, 1))
+        if ops.concat_buffer_supported(x, self.part_channels):
+            # no torch.cat: every layer's norm kernel writes its output into its channel slice of one buffer, the next layer
+            # reads that slice in place (pixel pitch = total channels), and in backward each layer adds its slice of the
+            # aggregation's input gradient on load (ops.ConcatBuffer)
+            B, _, H, W = x.shape
+            buf = ops.ConcatBuffer(B, H, W, sum(self.part_channels), torch.bfloat16, x.device)
+            parts = [ops.concat_copy_in(x, buf)]
+            cur = x
+            for layer in self.layers:
+                cur = layer(cur, into=buf)
+                parts.append(cur)
+            y = self.aggregation(ops.concat_read(buf, parts))
+        else:
+            feats = [x]
+            for layer in self.layers:
+                feats.append(layer(feats[-1]))
+            y = self.aggregation(torch.cat(feats, 1))
         return y + x if self.residual else y
 
 

@@ -30,6 +30,8 @@ struct NaGeom {
   int pix_per_thread;
   int act, has_add, has_lab, training;
   float eps, momentum;
+  int ldy;            // forward: pixel pitch of the OUTPUT (>= C: a channel slice of a concat buffer)
+  int ld_dy, ld_dy2;  // backward: pixel pitches of the output gradient and of its optional second part (dy + dy2)
 };
 
 __device__ __forceinline__ float act_fwd(float z, int act) {
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
         if (g.has_add) z += a[u][i];
         v[u][i] = ls * act_fwd(z, g.act) + lb;
       }
-      store_vec<T, VEC>(y + (size_t)(first + (n + u) * blockDim.y) * g.C + c0, v[u]);
+      store_vec<T, VEC>(y + (size_t)(first + (n + u) * blockDim.y) * g.ldy + c0, v[u]);
     }
   }
 }
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
 // Backward pass 1: per channel sum(dz), sum(dz * xhat), sum(dy * act(z)) [-> d lab_scale], sum(dy) [-> d lab_bias]
 template <typename T, int VEC, int UNROLL>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
-    const T* __restrict__ x, const T* __restrict__ addend, const T* __restrict__ dy,
+    const T* __restrict__ x, const T* __restrict__ addend, const T* __restrict__ dy, const T* __restrict__ dy2,
     const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ lab_scale,
     double* __restrict__ red_out, NaGeom g) {
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     for (int i = 0; i < VEC; ++i) acc[q][i] = 0.f;
   const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
   for (int n = 0; n < g.pix_per_thread; n += UNROLL) {
-    PackedVec<T, VEC> px[UNROLL], pa[UNROLL], pd[UNROLL];
+    PackedVec<T, VEC> px[UNROLL], pa[UNROLL], pd[UNROLL], pe[UNROLL];
     bool ok[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
@@ -235,7 +237,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
       if (ok[u]) {
         const size_t off = (size_t)pix * g.C + c0;
         px[u].load(x + off);
-        pd[u].load(dy + off);
+        pd[u].load(dy + (size_t)pix * g.ld_dy + c0);
+        if (dy2) pe[u].load(dy2 + (size_t)pix * g.ld_dy2 + c0);
         if (g.has_add) pa[u].load(addend + off);
       }
     }
@@ -245,6 +248,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
       float v[VEC], a[VEC], d[VEC];
       px[u].unpack(v);
       pd[u].unpack(d);
+      if (dy2) {  // the output feeds two consumers (next layer + a concat slice): their gradients are summed on load
+        float d2[VEC];
+        pe[u].unpack(d2);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) d[i] += d2[i];
+      }
       if (g.has_add) pa[u].unpack(a);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 // block row 0 also publishes dgamma/dbeta (fp32) and adds its channels' share of d lab.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
-    const T* __restrict__ x, const T* __restrict__ addend, const T* __restrict__ dy,
+    const T* __restrict__ x, const T* __restrict__ addend, const T* __restrict__ dy, const T* __restrict__ dy2,
     const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ lab_scale,
     const double* __restrict__ red_in, T* __restrict__ dx, T* __restrict__ dadd,
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
   const float ls = g.has_lab ? lab_scale[0] : 1.f;
   const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
   for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL_BWD) {
-    PackedVec<T, VEC> px[DFINE_NA_UNROLL_BWD], pa[DFINE_NA_UNROLL_BWD], pd[DFINE_NA_UNROLL_BWD];
+    PackedVec<T, VEC> px[DFINE_NA_UNROLL_BWD], pa[DFINE_NA_UNROLL_BWD], pd[DFINE_NA_UNROLL_BWD], pe[DFINE_NA_UNROLL_BWD];
     bool ok[DFINE_NA_UNROLL_BWD];
 #pragma unroll
     for (int u = 0; u < DFINE_NA_UNROLL_BWD; ++u) {
@@ -328,7 +337,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
       if (ok[u]) {
         const size_t off = (size_t)pix * g.C + c0;
         px[u].load(x + off);
-        pd[u].load(dy + off);
+        pd[u].load(dy + (size_t)pix * g.ld_dy + c0);
+        if (dy2) pe[u].load(dy2 + (size_t)pix * g.ld_dy2 + c0);
         if (g.has_add) pa[u].load(addend + off);
       }
     }
@@ -339,6 +349,12 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
       float v[VEC], a[VEC], d[VEC];
       px[u].unpack(v);
       pd[u].unpack(d);
+      if (dy2) {
+        float d2[VEC];
+        pe[u].unpack(d2);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) d[i] += d2[i];
+      }
       if (g.has_add) pa[u].unpack(a);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
@@ -392,6 +408,7 @@ static NaGeom make_geom(int n_pix, int C, int ppt, int act, bool has_add, bool h
   NaGeom g;
   g.n_pix = n_pix; g.C = C; g.pix_per_thread = ppt; g.act = act; g.has_add = has_add; g.has_lab = has_lab;
   g.training = training; g.eps = eps; g.momentum = momentum;
+  g.ldy = g.ld_dy = g.ld_dy2 = C;
   return g;
 }
 
@@ -399,7 +416,7 @@ template <typename T, int VEC>
 static int fwd_impl(const void* x, const void* addend, void* y, double* sums, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float* save_mean, float* save_rstd, const float* lab_scale,
                     const float* lab_bias, int n_pix, int C, int act, int training, float eps, float momentum, int phase,
-                    hipStream_t st) {
+                    int ldy, hipStream_t st) {
   NaLaunch R, A;
   if (int rc = plan<VEC>(&R, n_pix, C, reduce_target_blocks())) return rc;   // reductions: few blocks -> few contended atomics
   if (int rc = plan<VEC>(&A, n_pix, C, 1024)) return rc;  // streaming: ~4 blocks per CU, several pixels per thread
@@ -411,6 +428,7 @@ static int fwd_impl(const void* x, const void* addend, void* y, double* sums, co
   }
   if (phase == 1) return 0;
   NaGeom g = make_geom(n_pix, C, A.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, momentum);
+  g.ldy = ldy;
   hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), A.grid, A.block, (size_t)2 * A.block.x * VEC * sizeof(float), st, (const T*)x, (const T*)addend, (T*)y, sums, gamma, beta,
                      running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, g);
   DFINE_LAUNCH_CHECK();
@@ -418,7 +436,7 @@ static int fwd_impl(const void* x, const void* addend, void* y, double* sums, co
 }
 
 template <typename T, int VEC>
-static int bwd_impl(const void* x, const void* addend, const void* dy, const float* save_mean, const float* save_rstd,
+static int bwd_impl(const void* x, const void* addend, const void* dy, int ld_dy, const void* dy2, int ld_dy2, const float* save_mean, const float* save_rstd,
                     const float* gamma, const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
                     float* dgamma, float* dbeta, float* dlab_scale, float* dlab_bias, int n_pix, int C, int act, int training,
                     float eps, int phase, hipStream_t st) {
@@ -426,20 +444,21 @@ static int bwd_impl(const void* x, const void* addend, const void* dy, const flo
   if (int rc = plan<VEC>(&R, n_pix, C, reduce_target_blocks())) return rc;
   if (int rc = plan<VEC>(&A, n_pix, C, 1024)) return rc;
   NaGeom g = make_geom(n_pix, C, R.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, 0.f);
+  g.ld_dy = ld_dy, g.ld_dy2 = ld_dy2;
   if (phase != 2) {
     const size_t lds = (size_t)R.block.y * 4 * R.block.x * VEC * sizeof(float);
     static const int unroll = getenv("DFINE_BN_BWD_UNROLL") ? atoi(getenv("DFINE_BN_BWD_UNROLL")) : 2;
     if (unroll == 4)
-      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, 4>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy,
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, 4>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy, (const T*)dy2,
                          save_mean, save_rstd, gamma, beta, lab_scale, red, g);
     else
-      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, 2>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy,
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, 2>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy, (const T*)dy2,
                          save_mean, save_rstd, gamma, beta, lab_scale, red, g);
     DFINE_LAUNCH_CHECK();
   }
   if (phase == 1) return 0;
   g.pix_per_thread = A.ppt;
-  hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VEC>), A.grid, A.block, (size_t)6 * A.block.x * VEC * sizeof(float), st, (const T*)x, (const T*)addend, (const T*)dy, save_mean,
+  hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VEC>), A.grid, A.block, (size_t)6 * A.block.x * VEC * sizeof(float), st, (const T*)x, (const T*)addend, (const T*)dy, (const T*)dy2, save_mean,
                      save_rstd, gamma, beta, lab_scale, red, (T*)dx, (T*)dadd, dgamma, dbeta, dlab_scale, dlab_bias, g);
   DFINE_LAUNCH_CHECK();
   return 0;
@@ -470,18 +489,26 @@ extern "C" int dfine_bn_act_fwd(const void* x, const void* addend, void* y, int 
                                 const float* gamma, const float* beta, float* running_mean,
                                 float* running_var, float* save_mean, float* save_rstd,
                                 const float* lab_scale, const float* lab_bias, int n_pix, int C, int act, int training, float eps,
-                                float momentum, int phase, void* stream) {
+                                float momentum, int phase, int ldy, void* stream) {
   if (!x || !y || !gamma || !beta || !running_mean || !running_var) return DFINE_E_BADARG;
   if (training && (!sums || !save_mean || !save_rstd)) return DFINE_E_BADARG;
   if (n_pix <= 0 || C <= 0 || act < 0 || act > 2 || phase < 0 || phase > 2) return DFINE_E_BADARG;
   if ((lab_scale != nullptr) != (lab_bias != nullptr)) return DFINE_E_BADARG;
+  if (ldy == 0) ldy = C;
+  if (ldy < C) return DFINE_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-#define FWD(T, V) fwd_impl<T, V>(x, addend, y, sums, gamma, beta, running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, n_pix, C, act, training, eps, momentum, phase, st)
+  const int es = dtype == DFINE_DT_BF16 ? 2 : 4;
+  // a pitched output must keep the channel vectors aligned: pitch and base a multiple of the vector width
+#define FWD(T, V)                                                                                                                  \
+  ((ldy % V != 0 || (uintptr_t)y % (V * es) != 0)                                                                                  \
+       ? DFINE_E_UNSUPPORTED                                                                                                       \
+       : fwd_impl<T, V>(x, addend, y, sums, gamma, beta, running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, n_pix, C, \
+                        act, training, eps, momentum, phase, ldy, st))
   DFINE_NA_DISPATCH(FWD);
 #undef FWD
 }
 
-extern "C" int dfine_bn_act_bwd(const void* x, const void* addend, const void* dy, int dtype,
+extern "C" int dfine_bn_act_bwd(const void* x, const void* addend, const void* dy, int ld_dy, const void* dy2, int ld_dy2, int dtype,
                                 const float* save_mean, const float* save_rstd, const float* gamma,
                                 const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
                                 float* dgamma, float* dbeta, float* dlab_scale, float* dlab_bias, int n_pix,
@@ -490,8 +517,16 @@ extern "C" int dfine_bn_act_bwd(const void* x, const void* addend, const void* d
   if ((addend != nullptr) != (dadd != nullptr)) return DFINE_E_BADARG;
   if (lab_scale && (!dlab_scale || !dlab_bias)) return DFINE_E_BADARG;
   if (n_pix <= 0 || C <= 0 || act < 0 || act > 2 || phase < 0 || phase > 2) return DFINE_E_BADARG;
+  if (ld_dy == 0) ld_dy = C;
+  if (ld_dy2 == 0) ld_dy2 = C;
+  if (ld_dy < C || (dy2 && ld_dy2 < C)) return DFINE_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-#define BWD(T, V) bwd_impl<T, V>(x, addend, dy, save_mean, save_rstd, gamma, beta, lab_scale, red, dx, dadd, dgamma, dbeta, dlab_scale, dlab_bias, n_pix, C, act, training, eps, phase, st)
+  const int es = dtype == DFINE_DT_BF16 ? 2 : 4;
+#define BWD(T, V)                                                                                                                   \
+  ((ld_dy % V != 0 || (uintptr_t)dy % (V * es) != 0 || (dy2 && (ld_dy2 % V != 0 || (uintptr_t)dy2 % (V * es) != 0)))                \
+       ? DFINE_E_UNSUPPORTED                                                                                                        \
+       : bwd_impl<T, V>(x, addend, dy, ld_dy, dy2, ld_dy2, save_mean, save_rstd, gamma, beta, lab_scale, red, dx, dadd, dgamma, dbeta, \
+                        dlab_scale, dlab_bias, n_pix, C, act, training, eps, phase, st))
   DFINE_NA_DISPATCH(BWD);
 #undef BWD
 }

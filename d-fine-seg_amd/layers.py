@@ -85,9 +85,23 @@ class ConvNorm(nn.Module):
         delattr(self, "conv")
         delattr(self, self.norm_name)
 
-    def forward(self, x, addend=None, act=None):
+    def forward(self, x, addend=None, act=None, into=None):
         """``addend`` (same shape as the output) is added after the norm, before the activation;
-        ``act`` overrides the constructor's activation name (used by RepVgg: silu(a + b))."""
+        ``act`` overrides the constructor's activation name (used by RepVgg: silu(a + b)); ``into`` (an ops.ConcatBuffer):
+        the output becomes the buffer's next channel slice -- written there directly by the fused norm kernel."""
+        if into is not None:
+            norm = getattr(self, self.norm_name, None)
+            if x.is_cuda and isinstance(norm, (nn.BatchNorm2d, FrozenBatchNorm2d)):  # the fused norm kernel writes the slice
+                return self._forward(x, addend, act, (into, into.take(self.out_channels)))
+            return ops.concat_copy_in(self._forward(x, addend, act, None), into)  # deployed conv etc.: compute, then copy in
+        return self._forward(x, addend, act, None)
+
+    @property
+    def out_channels(self):
+        return (self.conv_bn_fused if hasattr(self, "conv_bn_fused") else self.conv).out_channels
+
+    def _forward(self, x, addend, act, slot):
+        """``slot`` = (buffer, first channel): only the fused-norm path can honour it; any other path returns None then."""
         if hasattr(self, "conv_bn_fused"):  # deployed: conv + bias (+ activation)
             y = ops.conv_bias_act(x, self.conv_bn_fused, act if act is not None else self.act_name, addend)
             return self.lab(y) if hasattr(self, "lab") else y
@@ -120,7 +134,10 @@ class ConvNorm(nn.Module):
             return ops.batch_norm_act(
                 x, norm.weight, norm.bias, norm.running_mean, norm.running_var, act_name,
                 lab.scale if lab is not None else None, lab.bias if lab is not None else None, addend,
-                training=batch_stats, momentum=getattr(norm, "momentum", 0.1) or 0.1, eps=norm.eps, ws=ws, have_stats=have_stats)
+                training=batch_stats, momentum=getattr(norm, "momentum", 0.1) or 0.1, eps=norm.eps, ws=ws, have_stats=have_stats,
+                slot=slot)
+        if slot is not None:
+            raise ops._lib.DfineHipError("ConvNorm: a concat slot needs the fused norm kernel")
         x = norm(x)
         if addend is not None:
             x = x + addend

@@ -419,20 +419,114 @@ def _nhwc(t):
     return v if v.is_contiguous() else v.contiguous()
 
 
+def _grad_rows(g, C):
+    """NHWC gradient view [B, H, W, C] -> (tensor, pixel pitch) readable by the BN backward kernels in place: pixels at a
+    constant pitch (dense, or a channel slice of a wider dense map) with 16-byte aligned channel vectors; else a dense copy."""
+    es = g.element_size()
+    vec = 16 // es
+    B, H, W, _ = g.shape
+    st = g.stride()
+    if (st[3] == 1 and st[2] >= C and st[1] == W * st[2] and st[0] == H * st[1] and st[2] % vec == 0
+            and g.data_ptr() % 16 == 0 and (C % vec == 0)):
+        return g, st[2]
+    return g.contiguous(), C
+
+
+class ConcatBuffer:
+    """One NHWC map [B, H, W, channels] that its producers fill by channel slice, in place of ``torch.cat`` (reference
+    hgnetv2.py:258-266 HG_Block, hybrid_encoder.py:213-239 RepNCSPELAN4): a fused BatchNorm writes its output straight into its
+    slice (``batch_norm_act(..., slot=(buffer, c0))``), other tensors are copied in (``concat_copy_in``), and ``concat_read``
+    hands the whole map to the consumer. In backward the consumer's input gradient is parked here (``grad``) instead of
+    being sliced through autograd: every producer reads its channel slice of it in place and adds it, on load, to the
+    gradient it receives from its other consumer -- no cat, no slice copies, no gradient-accumulation add kernels."""
+
+    def __init__(self, B, H, W, channels, dtype, device):
+        self.buf = torch.empty(B, H, W, channels, dtype=dtype, device=device)
+        self.grad = None
+        self.used = 0
+
+    def take(self, channels):
+        c0 = self.used
+        self.used += channels
+        if self.used > self.buf.shape[-1]:
+            raise _lib.DfineHipError("ConcatBuffer: more channels than reserved")
+        return c0
+
+
+class _ConcatCopyIn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, buffer, c0):
+        C = x.shape[1]
+        dst = buffer.buf[..., c0 : c0 + C]
+        dst.copy_(x.permute(0, 2, 3, 1))
+        ctx.slot = (buffer, c0, C)
+        ctx.set_materialize_grads(False)
+        return dst.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        buffer, c0, C = ctx.slot
+        out = buffer.grad[..., c0 : c0 + C].permute(0, 3, 1, 2) if buffer.grad is not None else None
+        if g is not None:
+            out = g if out is None else out + g
+        return out, None, None
+
+
+class _ConcatRead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, buffer, *parts):
+        ctx.buffer = buffer
+        return buffer.buf.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        gl = g.permute(0, 2, 3, 1)
+        ctx.buffer.grad = gl if gl.is_contiguous() else gl.contiguous()
+        return (None,) * (1 + len(ctx.needs_input_grad) - 1)
+
+
+def concat_copy_in(x, buffer):
+    """Copy ``x`` [B, C, H, W] into the next free channel slice of ``buffer``; returns the slice (an NCHW-shaped view)."""
+    return _ConcatCopyIn.apply(x, buffer, buffer.take(x.shape[1]))
+
+
+def concat_read(buffer, parts):
+    """The filled buffer as one [B, channels, H, W] channels_last tensor. ``parts`` (every slice written into it) tie the
+    producers into the autograd graph: their backward runs after this node's and finds the gradient in ``buffer.grad``."""
+    if buffer.used != buffer.buf.shape[-1]:
+        raise _lib.DfineHipError("concat_read: the buffer is not full")
+    return _ConcatRead.apply(buffer, *parts)
+
+
+def concat_buffer_supported(x, channel_counts):
+    """bf16 mode on the GPU, every part a multiple of 8 channels (16-byte channel vectors at every slice offset)."""
+    return (x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16)
+            and all(c % 8 == 0 for c in channel_counts))
+
+
 class _BatchNormAct(torch.autograd.Function):
     """BN (batch statistics, or frozen/running statistics) + addend + activation + LAB; see
     include/dfine_hip.h (dfine_bn_act_*)."""
 
     @staticmethod
     def forward(ctx, x, addend, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, eps, momentum, training,
-                ws=None, have_stats=False):
+                ws=None, have_stats=False, slot=None):
         _lib.require_gpu(x, gamma, beta)
         lib = _lib.load()
         B, C, H, W = x.shape
         xl = _nhwc(x)
         al = _nhwc(addend.to(x.dtype)) if addend is not None else None
         n_pix = B * H * W
-        y = torch.empty_like(xl)
+        ldy = 0
+        if slot is not None:  # write the output as a channel slice of a concat buffer (see ConcatBuffer)
+            y = slot[0].buf[..., slot[1] : slot[1] + C]
+            ldy = slot[0].buf.shape[-1]
+            if y.dtype != xl.dtype or tuple(y.shape) != tuple(xl.shape):
+                raise _lib.DfineHipError("batch_norm_act: the concat slot does not match the output")
+        else:
+            y = torch.empty_like(xl)
+        ctx.slot = slot
+        ctx.set_materialize_grads(False)
         # one zeroed workspace: fp64 sums [8 replicas][2C] (as 32C floats) | save_mean [C] | save_rstd [C]; with
         # ``have_stats`` the producing conv's epilogue (dfine_igemm_bf16) has already accumulated the sums into it
         if ws is None:
@@ -448,9 +542,9 @@ class _BatchNormAct(torch.autograd.Function):
         rc = 0
         if training and not have_stats:
             with _lib.timed("bn_stats", xl.numel() * es, f"{n_pix}x{C}"):
-                rc = lib.dfine_bn_act_fwd(*args, 1, _lib.stream_ptr())
+                rc = lib.dfine_bn_act_fwd(*args, 1, ldy, _lib.stream_ptr())
         with _lib.timed("bn_apply", (xl.numel() + y.numel() + (al.numel() if al is not None else 0)) * es, f"{n_pix}x{C}"):
-            rc = rc or lib.dfine_bn_act_fwd(*args, 2, _lib.stream_ptr())
+            rc = rc or lib.dfine_bn_act_fwd(*args, 2, ldy, _lib.stream_ptr())
         _lib.check(rc, "dfine_bn_act_fwd")
         if not training:  # frozen / eval statistics: the backward kernel reads them from the same two buffers
             save_mean = running_mean.detach().float()
@@ -466,7 +560,17 @@ class _BatchNormAct(torch.autograd.Function):
         act, eps, training, g_dtype, lab_dtype = ctx.cfg
         lib = _lib.load()
         n_pix, C = xl.numel() // xl.shape[-1], xl.shape[-1]
-        gy = _nhwc(grad_y.to(xl.dtype))
+        # the output gradient: what autograd hands over (the next layer's input gradient), plus -- for an output that was
+        # written into a concat buffer -- this layer's channel slice of the buffer's gradient, summed on load by the kernels
+        gy2, ld2 = None, 0
+        if ctx.slot is not None and ctx.slot[0].grad is not None:
+            gy2, ld2 = _grad_rows(ctx.slot[0].grad[..., ctx.slot[1] : ctx.slot[1] + C].to(xl.dtype), C)
+        if grad_y is None:
+            if gy2 is None:
+                return (None,) * 15
+            gy, ld1, gy2, ld2 = gy2, ld2, None, 0
+        else:
+            gy, ld1 = _grad_rows(grad_y.to(xl.dtype).permute(0, 2, 3, 1), C)
         dx = torch.empty_like(xl)
         dadd = torch.empty_like(xl) if al is not None else None
         # one zeroed workspace: fp64 reductions [8 replicas][4C] (as 64C floats) | dgamma [C] | dbeta [C] | dlab [2]
@@ -484,23 +588,24 @@ class _BatchNormAct(torch.autograd.Function):
                 dls, dlb = ls_p.grad, lb_p.grad
         es = xl.element_size()
         n_add = al.numel() if al is not None else 0
-        args = (_lib.ptr(xl), _lib.ptr(al), _lib.ptr(gy), _lib.dtype_code(xl), _lib.ptr(save_mean), _lib.ptr(save_rstd),
+        n_dy = 2 if gy2 is not None else 1
+        args = (_lib.ptr(xl), _lib.ptr(al), _lib.ptr(gy), ld1, _lib.ptr(gy2), ld2, _lib.dtype_code(xl), _lib.ptr(save_mean), _lib.ptr(save_rstd),
                 _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(ls32), _lib.ptr(red), _lib.ptr(dx), _lib.ptr(dadd), _lib.ptr(dgamma),
                 _lib.ptr(dbeta), _lib.ptr(dls) if ls32 is not None else None, _lib.ptr(dlb) if ls32 is not None else None,
                 n_pix, C, _ACT_CODES[act], training, eps)
         rc = 0
         if training or wants_param_grads:  # the reductions feed the batch-statistics terms and the parameter gradients
-            with _lib.timed("bn_bwd_reduce", (xl.numel() + gy.numel() + n_add) * es, f"{n_pix}x{C}"):
+            with _lib.timed("bn_bwd_reduce", ((2 + n_dy) * xl.numel() - xl.numel() + n_add) * es, f"{n_pix}x{C}"):
                 rc = lib.dfine_bn_act_bwd(*args, 1, _lib.stream_ptr())
-        with _lib.timed("bn_bwd_dx", (xl.numel() + 2 * gy.numel() + 2 * n_add) * es, f"{n_pix}x{C}"):
+        with _lib.timed("bn_bwd_dx", ((2 + n_dy) * xl.numel() + 2 * n_add) * es, f"{n_pix}x{C}"):
             rc = rc or lib.dfine_bn_act_bwd(*args, 2, _lib.stream_ptr())
         _lib.check(rc, "dfine_bn_act_bwd")
         if direct or not wants_param_grads:
-            return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None) + (None,) * 12
+            return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None) + (None,) * 13
         return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None,
                 dgamma.to(g_dtype), dbeta.to(g_dtype), None, None,
                 dlab[0:1].to(lab_dtype) if ls32 is not None else None,
-                dlab[1:2].to(lab_dtype) if ls32 is not None else None, None, None, None, None, None, None)
+                dlab[1:2].to(lab_dtype) if ls32 is not None else None, None, None, None, None, None, None, None)
 
 
 def bn_workspace(channels, device):
@@ -510,7 +615,7 @@ def bn_workspace(channels, device):
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, lab_scale=None, lab_bias=None,
-                   addend=None, training=True, momentum=0.1, eps=1e-5, ws=None, have_stats=False):
+                   addend=None, training=True, momentum=0.1, eps=1e-5, ws=None, have_stats=False, slot=None):
     """Fused ``lab_scale * act(batch_norm(x) + addend) + lab_bias`` on a channels_last map
     (float32 or bfloat16). ``lab_scale`` / ``lab_bias`` are float tensors [1] (both or neither);
     ``act`` is None, "relu" or "silu". In training mode the running statistics are updated in place exactly like
@@ -518,7 +623,7 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, lab_scal
     if x.dtype not in (torch.float32, torch.bfloat16):
         x = x.float()
     return _BatchNormAct.apply(x, addend, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, float(eps),
-                               float(momentum), bool(training), ws, bool(have_stats))
+                               float(momentum), bool(training), ws, bool(have_stats), slot)
 
 
 def batch_norm_act_supported(x, channels):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 3
+#define DFINE_ABI_VERSION 4
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -154,14 +154,19 @@ int dfine_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* wor
  *   phase: each direction is two kernels (forward: statistics, apply; backward: reductions, dx).
  *       0 = launch both, 1 = only the first, 2 = only the second (so a caller can time them apart).
  * Any C (the widest channel vector <= 16 bytes that divides C is used).
+ * Pitches (elements; 0 = C): `ldy` lets the forward write its output as a CHANNEL SLICE of a wider map (the concat buffer of
+ *   an HG block / ELAN block: torch.cat disappears); in the backward the output gradient is read with pitch `ld_dy` and an
+ *   optional second part `dy2` (pitch `ld_dy2`) is added on load -- a layer whose output feeds the next layer AND a concat
+ *   receives (next layer's input gradient) + (a channel slice of the concat's gradient) without an add kernel or a copy.
+ *   Pitches and bases must keep the channel vectors aligned (multiples of the vector width), else DFINE_E_UNSUPPORTED.
  * ------------------------------------------------------------------------------------- */
 int dfine_bn_act_fwd(const void* x, const void* addend, void* y, int dtype, double* sums,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float* save_mean, float* save_rstd, const float* lab_scale, const float* lab_bias,
                      int n_pix, int C, int act, int training, float eps, float momentum, int phase,
-                     void* stream);
-int dfine_bn_act_bwd(const void* x, const void* addend, const void* dy, int dtype,
-                     const float* save_mean, const float* save_rstd, const float* gamma,
+                     int ldy, void* stream);
+int dfine_bn_act_bwd(const void* x, const void* addend, const void* dy, int ld_dy, const void* dy2, int ld_dy2,
+                     int dtype, const float* save_mean, const float* save_rstd, const float* gamma,
                      const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
                      float* dgamma, float* dbeta, float* dlab_scale, float* dlab_bias, int n_pix, int C,
                      int act, int training, float eps, int phase, void* stream);

@@ -1,0 +1,115 @@
+"""ops.ConcatBuffer: the HG block without torch.cat. Producers write channel slices of one buffer (fused norm kernel with an
+output pitch), consumers read slices in place, and in backward every producer adds its slice of the concat's gradient on load
+(dfine_bn_act_bwd's dy2). Reference: the same block run through torch.cat + autograd's own gradient accumulation."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_block(block, x, mode, monkeypatch):
+    """mode: "buffer" (bf16, ConcatBuffer), "cat" (bf16, torch.cat + autograd's accumulation), "fp32" (no autocast: the truth)."""
+    from dfine_seg_amd import ops
+
+    if mode == "cat":
+        monkeypatch.setattr(ops, "concat_buffer_supported", lambda *a, **k: False)
+    xx = (x.float() if mode == "fp32" else x.clone()).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode != "fp32"):
+        y = block(xx)
+    w = torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)
+    (y.float() * w).sum().backward()
+    grads = {n: p.grad.clone() for n, p in block.named_parameters()}
+    monkeypatch.undo()
+    return y.detach(), xx.grad.detach(), grads
+
+
+@pytest.mark.parametrize("light,k,residual", [(True, 5, True), (False, 3, False)])
+def test_hg_block_without_cat_matches_the_cat_path(hip_lib, monkeypatch, light, k, residual):
+    from dfine_seg_amd.backbone import Block
+
+    torch.manual_seed(0)
+    kw = dict(act="relu", lab=True, norm_name="bn", frozen_norm=False)
+    c_in = 64
+    block = Block(c_in, 32, 64, 3, k, light, residual, kw).cuda().to(memory_format=torch.channels_last).train()
+    x = torch.randn(4, c_in, 24, 24, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    cat_block, fp32_block = copy.deepcopy(block), copy.deepcopy(block)
+    y0, gx0, g0 = _run_block(cat_block, x, "cat", monkeypatch)
+    y1, gx1, g1 = _run_block(block, x, "buffer", monkeypatch)
+    _, gxr, gr = _run_block(fp32_block, x, "fp32", monkeypatch)
+    # forward: the same kernels on the same values, only the addresses differ
+    assert torch.equal(y0, y1)
+    # running statistics were updated identically
+    for (n, b0), (_, b1) in zip(cat_block.named_buffers(), block.named_buffers()):
+        assert torch.equal(b0, b1), n
+    # backward: a two-consumer gradient is summed in fp32 on load instead of being rounded to a bf16 tensor first, so the two
+    # bf16 runs are a bf16 round-off apart; measured against the fp32 run the buffer path must be no worse than the cat path
+    # (sums with heavy cancellation -- the LAB bias gradient is the sum of ALL gradient elements -- move by percents in both)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+    assert rel(gx1, gx0) < 1e-2, rel(gx1, gx0)
+    assert rel(gx1, gxr) < max(1.25 * rel(gx0, gxr), 1e-2)
+    for n in g0:
+        if light and n.endswith("conv1.bn.weight"):
+            # a per-channel scale in front of a depthwise conv + BatchNorm cannot change the output (the second norm divides
+            # it out): the true gradient is 0 and every run holds nothing but round-off there
+            assert float(g1[n].abs().max()) < 1.0
+            continue
+        assert rel(g1[n], gr[n]) < max(1.25 * rel(g0[n], gr[n]), 2e-2), (n, rel(g1[n], gr[n]), rel(g0[n], gr[n]))
+
+
+def test_norm_kernel_writes_a_slice_and_sums_two_gradients(hip_lib):
+    """dfine_bn_act_fwd with an output pitch and dfine_bn_act_bwd with (dy, dy2) against the dense call on dy + dy2."""
+    from dfine_seg_amd import ops
+
+    torch.manual_seed(1)
+    B, C, H, W, CT, c0 = 3, 32, 10, 12, 96, 40
+    x = torch.randn(B, C, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    gamma = (torch.rand(C, device="cuda") + 0.5).requires_grad_(True)
+    beta = torch.randn(C, device="cuda").requires_grad_(True)
+    g_next = torch.randn(B, C, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    g_cat = torch.randn(B, H, W, CT, device="cuda").bfloat16()
+
+    def stats():
+        return torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+
+    # dense reference: one gradient = bf16(dy + dy2 slice) the way autograd would accumulate it... in fp32 here, so the
+    # comparison isolates the kernels from that rounding
+    xr = x.clone().requires_grad_(True)
+    rm, rv = stats()
+    y_ref = ops.batch_norm_act(xr, gamma, beta, rm, rv, "relu", training=True)
+    total = (g_next.float() + g_cat[..., c0 : c0 + C].permute(0, 3, 1, 2).float())
+    y_ref.backward(total.bfloat16())
+    ref = (xr.grad.clone(), gamma.grad.clone(), beta.grad.clone())
+    gamma.grad = beta.grad = None
+
+    buf = ops.ConcatBuffer(B, H, W, CT, torch.bfloat16, "cuda")
+    buf.buf.fill_(7.0)
+    buf.used = c0
+    xs = x.clone().requires_grad_(True)
+    rm2, rv2 = stats()
+    y = ops.batch_norm_act(xs, gamma, beta, rm2, rv2, "relu", training=True, slot=(buf, buf.take(C)))
+    assert y.data_ptr() == buf.buf[..., c0:].data_ptr() and torch.equal(y, y_ref)
+    assert float((buf.buf[..., :c0] - 7).abs().max()) == 0 and float((buf.buf[..., c0 + C :] - 7).abs().max()) == 0  # neighbours untouched
+    assert torch.equal(rm, rm2) and torch.equal(rv, rv2)
+    buf.grad = g_cat
+    y.backward(g_next)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+    assert rel(xs.grad, ref[0]) < 6e-3, rel(xs.grad, ref[0])  # the reference rounded the summed gradient to bf16 first
+    assert rel(gamma.grad, ref[1]) < 6e-3 and rel(beta.grad, ref[2]) < 6e-3
+    # only the concat's gradient (the last layer of a block has no other consumer)
+    xs.grad = gamma.grad = beta.grad = None
+    rm3, rv3 = stats()
+    buf2 = ops.ConcatBuffer(B, H, W, CT, torch.bfloat16, "cuda")
+    buf2.used = c0
+    x3 = x.clone().requires_grad_(True)
+    y3 = ops.batch_norm_act(x3, gamma, beta, rm3, rv3, "relu", training=True, slot=(buf2, buf2.take(C)))
+    buf2.used = CT
+    full = ops.concat_read(buf2, [y3])
+    full.backward(g_cat.permute(0, 3, 1, 2))
+    x4 = x.clone().requires_grad_(True)
+    g3 = (gamma.grad.clone(), beta.grad.clone())
+    gamma.grad = beta.grad = None
+    rm4, rv4 = stats()
+    ops.batch_norm_act(x4, gamma, beta, rm4, rv4, "relu", training=True).backward(g_cat[..., c0 : c0 + C].permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last))
+    assert torch.equal(x3.grad, x4.grad) and torch.allclose(g3[0], gamma.grad, rtol=1e-5, atol=1e-5)
