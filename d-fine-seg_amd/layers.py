@@ -91,7 +91,9 @@ class ConvNorm(nn.Module):
         the output becomes the buffer's next channel slice -- written there directly by the fused norm kernel."""
         if into is not None:
             norm = getattr(self, self.norm_name, None)
-            if x.is_cuda and isinstance(norm, (nn.BatchNorm2d, FrozenBatchNorm2d)):  # the fused norm kernel writes the slice
+            if (x.is_cuda and isinstance(norm, (nn.BatchNorm2d, FrozenBatchNorm2d))
+                    and ops.batch_norm_act_supported(x.to(torch.bfloat16) if torch.is_autocast_enabled() else x, self.out_channels)):
+                # the fused norm kernel writes the slice
                 return self._forward(x, addend, act, (into, into.take(self.out_channels)))
             return ops.concat_copy_in(self._forward(x, addend, act, None), into)  # deployed conv etc.: compute, then copy in
         return self._forward(x, addend, act, None)
