@@ -33,8 +33,8 @@ SIGNATURES = {
     "dfine_conv_wgrad": [_c_void_p] * 3 + [_c_int] * 13 + [_c_void_p],
     "dfine_fdr_head_fwd": [_c_void_p] * 6 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, _c_void_p],
     "dfine_fdr_head_bwd": [_c_void_p] * 7 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, _c_void_p],
-    "dfine_stem_pool_fwd": [_c_void_p, _c_int, _c_void_p] + [_c_int] * 4 + [_c_void_p],
-    "dfine_stem_pool_bwd": [_c_void_p, _c_void_p, _c_int, _c_void_p] + [_c_int] * 4 + [_c_void_p],
+    "dfine_stem_pool_fwd": [_c_void_p, _c_int, _c_void_p] + [_c_int] * 5 + [_c_void_p],
+    "dfine_stem_pool_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p] + [_c_int] * 4 + [_c_void_p],
     "dfine_mask_loss_stats": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_int] * 4 + [_c_void_p],
     "dfine_mask_loss_grad": [_c_void_p, _c_int] + [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p],
     "dfine_add_layernorm_fwd": [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 6 + [ctypes.c_longlong, _c_int, ctypes.c_float, ctypes.c_float, _c_void_p],
@@ -58,7 +58,7 @@ SIGNATURES = {
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int, _c_void_p, _c_int, _c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 IGEMM_MAX_TAPS = 16

@@ -23,9 +23,18 @@ class Stem(nn.Module):
 
     def forward(self, x):
         u = self.stem1(x)
-        branch = self.stem2b(self.stem2a(u))  # 2x2 convs on the map zero-extended by one row / column (no padded copy)
+        c = u.shape[1]
+        if ops.stem_pool_supported(u) and ops.concat_buffer_supported(u, [c, c]) and u.dtype == torch.bfloat16:
+            # pooled map and conv branch are written straight into the two halves of one buffer (no torch.cat on the largest
+            # maps of the model: [B, 48, 320, 320] at 640x640), and read their halves of stem3's input gradient in place
+            B, _, H, W = u.shape
+            buf = ops.ConcatBuffer(B, H, W, 2 * c, torch.bfloat16, u.device)
+            pooled = ops.stem_pool(u, into=buf)  # HIP: max-pool of the zero-extended map, no padded copy
+            branch = self.stem2b(self.stem2a(u), into=buf)  # 2x2 convs on the zero-extended map (no padded copy)
+            return self.stem4(self.stem3(ops.concat_read(buf, [pooled, branch])))
+        branch = self.stem2b(self.stem2a(u))
         if ops.stem_pool_supported(u):
-            pooled = ops.stem_pool(u)  # HIP: max-pool of the zero-extended map, no padded copy
+            pooled = ops.stem_pool(u)
         else:
             pooled = F.max_pool2d(F.pad(u, (0, 1, 0, 1)), 2, stride=1, ceil_mode=True)
         return self.stem4(self.stem3(torch.cat([pooled, branch], 1)))

@@ -371,6 +371,16 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
   }
 }
 
+static int apply_target_blocks() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DFINE_BN_APPLY_BLOCKS");
+    v = e ? atoi(e) : 1024;
+    if (v < 64) v = 64;
+  }
+  return v;
+}
+
 static int reduce_target_blocks() {
   static int v = -1;
   if (v < 0) {
@@ -419,7 +429,7 @@ static int fwd_impl(const void* x, const void* addend, void* y, double* sums, co
                     int ldy, hipStream_t st) {
   NaLaunch R, A;
   if (int rc = plan<VEC>(&R, n_pix, C, reduce_target_blocks())) return rc;   // reductions: few blocks -> few contended atomics
-  if (int rc = plan<VEC>(&A, n_pix, C, 1024)) return rc;  // streaming: ~4 blocks per CU, several pixels per thread
+  if (int rc = plan<VEC>(&A, n_pix, C, apply_target_blocks())) return rc;  // streaming: ~4 blocks per CU, several pixels per thread
   if (training && phase != 2) {
     NaGeom g = make_geom(n_pix, C, R.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, momentum);
     const size_t lds = (size_t)R.block.y * 2 * R.block.x * VEC * sizeof(float);
@@ -442,7 +452,7 @@ static int bwd_impl(const void* x, const void* addend, const void* dy, int ld_dy
                     float eps, int phase, hipStream_t st) {
   NaLaunch R, A;
   if (int rc = plan<VEC>(&R, n_pix, C, reduce_target_blocks())) return rc;
-  if (int rc = plan<VEC>(&A, n_pix, C, 1024)) return rc;
+  if (int rc = plan<VEC>(&A, n_pix, C, apply_target_blocks())) return rc;
   NaGeom g = make_geom(n_pix, C, R.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, 0.f);
   g.ld_dy = ld_dy, g.ld_dy2 = ld_dy2;
   if (phase != 2) {

@@ -24,7 +24,7 @@ __device__ __forceinline__ void load_px(const T* x, int b, int y, int xx, int H,
 
 template <typename T>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W,
-                                                       int C) {
+                                                       int C, int ldy) {
   constexpr int V = VecTraits<T>::kElems;
   const int cpp = C / V;  // chunks per pixel
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,12 +45,12 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* __restrict__ x, 
   load_px(x, b, yy + 1, xx + 1, H, W, C, c0, a);
 #pragma unroll
   for (int i = 0; i < V; ++i) o[i] = a[i] > o[i] ? a[i] : o[i];
-  store_vec<T, V>(y + (((size_t)b * H + yy) * W + xx) * C + c0, o);
+  store_vec<T, V>(y + (((size_t)b * H + yy) * W + xx) * ldy + c0, o);  // ldy > C: a channel slice of a concat buffer
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gy,
-                                                       T* __restrict__ gx, int B, int H, int W, int C) {
+                                                       T* __restrict__ gx, int B, int H, int W, int C, int ld_gy) {
   constexpr int V = VecTraits<T>::kElems;
   const int cpp = C / V;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, 
       const int oy = yy + wy - 1, ox = xx + wx - 1;
       if (oy < 0 || ox < 0) continue;
       float g[V];
-      load_vec<T, V>(gy + (((size_t)b * H + oy) * W + ox) * C + c0, g);
+      load_vec<T, V>(gy + (((size_t)b * H + oy) * W + ox) * ld_gy + c0, g);
       const int mine = (1 - wy) * 2 + (1 - wx);  // scan index of this pixel inside that window
 #pragma unroll
       for (int i = 0; i < V; ++i) {
@@ -100,14 +100,17 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, 
 }
 
 template <typename T>
-static int launch_pool(bool fwd, const void* x, const void* gy, void* out, int B, int H, int W, int C, hipStream_t st) {
+static int launch_pool(bool fwd, const void* x, const void* gy, void* out, int B, int H, int W, int C, int ld, hipStream_t st) {
   constexpr int V = VecTraits<T>::kElems;
   if (C % V != 0) return DFINE_E_UNSUPPORTED;
+  if (ld == 0) ld = C;
+  // the pitched operand (forward: y, backward: gy) must keep its channel vectors aligned
+  if (ld < C || ld % V != 0 || (uintptr_t)(fwd ? out : gy) % (V * sizeof(T)) != 0) return ld < C ? DFINE_E_BADARG : DFINE_E_UNSUPPORTED;
   const size_t items = (size_t)B * H * W * (C / V);
   const size_t blocks = (items + 255) / 256;
   if (blocks > 0x7fffffffULL) return DFINE_E_UNSUPPORTED;
-  if (fwd) hipLaunchKernelGGL(pool_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (T*)out, B, H, W, C);
-  else hipLaunchKernelGGL(pool_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (const T*)gy, (T*)out, B, H, W, C);
+  if (fwd) hipLaunchKernelGGL(pool_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (T*)out, B, H, W, C, ld);
+  else hipLaunchKernelGGL(pool_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (const T*)gy, (T*)out, B, H, W, C, ld);
   DFINE_LAUNCH_CHECK();
   return 0;
 }
@@ -116,19 +119,19 @@ static int launch_pool(bool fwd, const void* x, const void* gy, void* out, int B
 
 using namespace dfine;
 
-extern "C" int dfine_stem_pool_fwd(const void* x, int dtype, void* y, int B, int H, int W, int C, void* stream) {
+extern "C" int dfine_stem_pool_fwd(const void* x, int dtype, void* y, int B, int H, int W, int C, int ldy, void* stream) {
   if (!x || !y) return DFINE_E_BADARG;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return DFINE_E_BADARG;
-  if (dtype == DFINE_DT_F32) return launch_pool<float>(true, x, nullptr, y, B, H, W, C, (hipStream_t)stream);
-  if (dtype == DFINE_DT_BF16) return launch_pool<bf16_t>(true, x, nullptr, y, B, H, W, C, (hipStream_t)stream);
+  if (dtype == DFINE_DT_F32) return launch_pool<float>(true, x, nullptr, y, B, H, W, C, ldy, (hipStream_t)stream);
+  if (dtype == DFINE_DT_BF16) return launch_pool<bf16_t>(true, x, nullptr, y, B, H, W, C, ldy, (hipStream_t)stream);
   return DFINE_E_UNSUPPORTED;
 }
 
-extern "C" int dfine_stem_pool_bwd(const void* x, const void* gy, int dtype, void* gx, int B, int H, int W, int C,
+extern "C" int dfine_stem_pool_bwd(const void* x, const void* gy, int ld_gy, int dtype, void* gx, int B, int H, int W, int C,
                                    void* stream) {
   if (!x || !gy || !gx) return DFINE_E_BADARG;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return DFINE_E_BADARG;
-  if (dtype == DFINE_DT_F32) return launch_pool<float>(false, x, gy, gx, B, H, W, C, (hipStream_t)stream);
-  if (dtype == DFINE_DT_BF16) return launch_pool<bf16_t>(false, x, gy, gx, B, H, W, C, (hipStream_t)stream);
+  if (dtype == DFINE_DT_F32) return launch_pool<float>(false, x, gy, gx, B, H, W, C, ld_gy, (hipStream_t)stream);
+  if (dtype == DFINE_DT_BF16) return launch_pool<bf16_t>(false, x, gy, gx, B, H, W, C, ld_gy, (hipStream_t)stream);
   return DFINE_E_UNSUPPORTED;
 }

@@ -697,16 +697,25 @@ def criterion_head(logits, boxes, corners, ref_points, teacher_corners, teacher_
 
 class _StemPool(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, slot):
         _lib.require_gpu(x)
         lib = _lib.load()
         xl = _nhwc(x)
         B, H, W, C = xl.shape
-        y = torch.empty_like(xl)
+        ldy = 0
+        if slot is not None:  # the pooled map is a channel slice of a concat buffer
+            y = slot[0].buf[..., slot[1] : slot[1] + C]
+            ldy = slot[0].buf.shape[-1]
+            if y.dtype != xl.dtype or tuple(y.shape) != tuple(xl.shape):
+                raise _lib.DfineHipError("stem_pool: the concat slot does not match the output")
+        else:
+            y = torch.empty_like(xl)
         with _lib.timed("stem_pool_fwd", 2 * xl.numel() * xl.element_size()):
-            rc = lib.dfine_stem_pool_fwd(_lib.ptr(xl), _lib.dtype_code(xl), _lib.ptr(y), B, H, W, C, _lib.stream_ptr())
+            rc = lib.dfine_stem_pool_fwd(_lib.ptr(xl), _lib.dtype_code(xl), _lib.ptr(y), B, H, W, C, ldy, _lib.stream_ptr())
         _lib.check(rc, "dfine_stem_pool_fwd")
         ctx.save_for_backward(xl)
+        ctx.slot = slot
+        ctx.set_materialize_grads(False)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -714,18 +723,26 @@ class _StemPool(torch.autograd.Function):
         (xl,) = ctx.saved_tensors
         lib = _lib.load()
         B, H, W, C = xl.shape
-        gyl = _nhwc(gy.to(xl.dtype))
+        if ctx.slot is not None and ctx.slot[0].grad is not None:  # this map's slice of the concat's gradient, read in place
+            g2 = ctx.slot[0].grad[..., ctx.slot[1] : ctx.slot[1] + C].to(xl.dtype)
+            gy = g2 if gy is None else g2 + gy.permute(0, 2, 3, 1)
+        elif gy is None:
+            return None, None
+        else:
+            gy = gy.to(xl.dtype).permute(0, 2, 3, 1)
+        gyl, ld = _grad_rows(gy, C)
         gx = torch.empty_like(xl)
         with _lib.timed("stem_pool_bwd", 3 * xl.numel() * xl.element_size()):
-            rc = lib.dfine_stem_pool_bwd(_lib.ptr(xl), _lib.ptr(gyl), _lib.dtype_code(xl), _lib.ptr(gx), B, H, W, C, _lib.stream_ptr())
+            rc = lib.dfine_stem_pool_bwd(_lib.ptr(xl), _lib.ptr(gyl), ld, _lib.dtype_code(xl), _lib.ptr(gx), B, H, W, C, _lib.stream_ptr())
         _lib.check(rc, "dfine_stem_pool_bwd")
-        return gx.permute(0, 3, 1, 2)
+        return gx.permute(0, 3, 1, 2), None
 
 
-def stem_pool(x):
+def stem_pool(x, into=None):
     """``F.max_pool2d(F.pad(x, (0, 1, 0, 1)), 2, stride=1, ceil_mode=True)`` on a channels_last map
-    [B, C, H, W] -> [B, C, H, W] (HGNetv2 stem, hgnetv2.py:213-224), HIP, no padded copy."""
-    return _StemPool.apply(x)
+    [B, C, H, W] -> [B, C, H, W] (HGNetv2 stem, hgnetv2.py:213-224), HIP, no padded copy. ``into`` (a ConcatBuffer): the
+    result becomes the buffer's next channel slice."""
+    return _StemPool.apply(x, (into, into.take(x.shape[1])) if into is not None else None)
 
 
 def stem_pool_supported(x):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 4
+#define DFINE_ABI_VERSION 5
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -303,9 +303,11 @@ int dfine_fdr_head_bwd(const float* corners, const float* ref_boxes, const float
  *   x, y, gy, gx [B, H, W, C] bf16 or f32 (dtype); C % 8 == 0 (bf16) / C % 4 == 0 (f32).
  * Backward sends each output gradient to the first maximum of its window in scan order (ATen's
  * rule); gradients that fall on the zero extension are dropped. gx is written, not accumulated.
+ * `ldy` / `ld_gy` (elements, 0 = C): pixel pitch of the forward's output / the backward's output gradient, so the pooled map
+ * can be one channel slice of the stem's concat buffer (hgnetv2.py:222 torch.cat([x1, x2], dim=1) disappears).
  * ------------------------------------------------------------------------------------- */
-int dfine_stem_pool_fwd(const void* x, int dtype, void* y, int B, int H, int W, int C, void* stream);
-int dfine_stem_pool_bwd(const void* x, const void* gy, int dtype, void* gx, int B, int H, int W, int C,
+int dfine_stem_pool_fwd(const void* x, int dtype, void* y, int B, int H, int W, int C, int ldy, void* stream);
+int dfine_stem_pool_bwd(const void* x, const void* gy, int ld_gy, int dtype, void* gx, int B, int H, int W, int C,
                         void* stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -113,3 +113,24 @@ def test_norm_kernel_writes_a_slice_and_sums_two_gradients(hip_lib):
     rm4, rv4 = stats()
     ops.batch_norm_act(x4, gamma, beta, rm4, rv4, "relu", training=True).backward(g_cat[..., c0 : c0 + C].permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last))
     assert torch.equal(x3.grad, x4.grad) and torch.allclose(g3[0], gamma.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_stem_without_cat_matches_the_cat_path(hip_lib, monkeypatch):
+    """HGNetv2 stem: the max-pooled map (dfine_stem_pool_fwd with an output pitch) and the 2x2-conv branch fill the two halves
+    of one buffer; in backward the pool reads its half of stem3's input gradient in place (ld_gy). Forward bit-equal to the
+    torch.cat path; gradients no worse than the cat path against the fp32 run."""
+    from dfine_seg_amd.backbone import Stem
+
+    torch.manual_seed(0)
+    kw = dict(act="relu", lab=True, norm_name="bn", frozen_norm=False)
+    stem = Stem(3, 24, 32, kw).cuda().to(memory_format=torch.channels_last).train()
+    x = torch.randn(2, 3, 64, 96, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    cat_stem, fp32_stem = copy.deepcopy(stem), copy.deepcopy(stem)
+    y0, gx0, g0 = _run_block(cat_stem, x, "cat", monkeypatch)
+    y1, gx1, g1 = _run_block(stem, x, "buffer", monkeypatch)
+    _, gxr, gr = _run_block(fp32_stem, x, "fp32", monkeypatch)
+    assert torch.equal(y0, y1)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+    assert rel(gx1, gxr) < max(1.25 * rel(gx0, gxr), 1e-2), (rel(gx1, gxr), rel(gx0, gxr))
+    for n in g0:
+        assert rel(g1[n], gr[n]) < max(1.25 * rel(g0[n], gr[n]), 2e-2), (n, rel(g1[n], gr[n]), rel(g0[n], gr[n]))

@@ -1,12 +1,13 @@
 #!/bin/bash
-# sweep of the BN backward reduction grid size (env knob read by normact.hip); per-shape timings of the dominant maps
-for n in ${@:-256 384 512}; do
-  DFINE_BN_REDUCE_BLOCKS=$n python bench.py --steps 8 --warmup 4 --no-cpu-baseline --shapes 2>/dev/null | tail -1 > /tmp/b.json
-  python - "$n" <<'PY'
+# sweep of the BN grid sizes (env knobs read by normact.hip): DFINE_BN_APPLY_BLOCKS (apply / dx kernels), DFINE_BN_REDUCE_BLOCKS
+knob=${1:-DFINE_BN_APPLY_BLOCKS}; shift
+for n in ${@:-512 1024 2048 4096}; do
+  env $knob=$n python bench.py --steps 8 --warmup 4 --no-cpu-baseline --shapes 2>/dev/null | tail -1 > /tmp/b.json
+  python - "$knob=$n" <<'PY'
 import json, sys
 d = json.load(open('/tmp/b.json')); k = d["roofline"]["kernels"]
-tot = sum(v["ms_per_step"] for n, v in k.items() if n.startswith("bn_bwd_reduce") or n.startswith("bn_stats"))
-print("blocks", sys.argv[1], d["value"], d["ms_per_step"], "reduce+stats ms", round(tot, 3),
-      {n.split()[-1]: v["avg_us"] for n, v in k.items() if n.startswith("bn_bwd_reduce") and n.split()[-1] in ("51200x128", "204800x128", "12800x256", "819200x32")})
+tot = {f: round(sum(v["ms_per_step"] for n, v in k.items() if n.startswith(f)), 3) for f in ("bn_apply", "bn_bwd_dx", "bn_bwd_reduce")}
+print(sys.argv[1], d["value"], d["ms_per_step"], tot,
+      {n: v["avg_us"] for n, v in k.items() if n.split()[0] in ("bn_apply", "bn_bwd_dx") and n.split()[-1] in ("51200x128", "204800x128", "12800x256")})
 PY
 done
