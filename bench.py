@@ -96,8 +96,8 @@ def cpu_baseline(model, args, num_classes=80):
 
 TIMER_TO_DEVICE_KERNEL = {
     "bn_stats": "bn_stats_kernel", "bn_apply": "bn_apply_kernel", "bn_bwd_reduce": "bn_bwd_reduce_kernel",
-    "bn_bwd_dx": "bn_bwd_dx_kernel", "wgrad": "wgrad_kernel", "msda_fwd": "msda_fwd_kernel", "msda_bwd": "msda_bwd_kernel",
-    "dwconv_fwd": "dwconv_fwd_kernel", "dwconv_bwd_data": "dwconv_bwd_data_kernel", "dwconv_bwd_weight": "dwconv_bwd_weight_kernel",
+    "bn_bwd_dx": "bn_bwd_dx_kernel", "wgrad": "wgrad_group_kernel", "msda_fwd": "msda_fwd_kernel", "msda_bwd": "msda_bwd_kernel",
+    "dwconv_fwd": "dwconv_strip_kernel", "dwconv_bwd_data": "dwconv_strip_kernel", "dwconv_bwd_weight": "dwconv_bwd_weight_kernel",
     "criterion_head": "criterion_head_kernel", "grad_sumsq": "grad_sumsq_kernel", "adamw_ema_step": "adamw_ema_kernel",
     "fdr_head_fwd": "fdr_head_fwd_kernel", "fdr_head_bwd": "fdr_head_bwd_kernel", "stem_pool_fwd": "pool_fwd_kernel",
     "stem_pool_bwd": "pool_bwd_kernel", "add_layernorm_fwd": "add_ln_fwd_kernel", "add_layernorm_bwd": "add_ln_bwd_kernel",

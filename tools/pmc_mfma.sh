@@ -23,7 +23,8 @@ for r in rows:
     if int(r["Dispatch_Id"]) <= start:
         continue
     n = r["Kernel_Name"]
-    if "wgrad_kernel" in n: k = "dfine::wgrad_kernel (weight gradients)"
+    if "wgrad_group_kernel" in n: k = "dfine::wgrad_group_kernel (grouped weight gradients)"
+    elif "wgrad_kernel" in n: k = "dfine::wgrad_kernel (single-problem weight gradients: stem)"
     elif "dfine::igemm_kernel" in n and "true>" in n.split("(")[0]: k = "dfine::igemm_kernel, gathered (k x k / strided conv forward + input gradient)"
     elif "dfine::igemm_kernel" in n: k = "dfine::igemm_kernel, plain rows (1x1 conv + Linear forward / input gradient)"
     elif "dfine::attn" in n: k = "dfine::attn_* (self-attention forward / backward)"
