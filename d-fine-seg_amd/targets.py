@@ -113,9 +113,11 @@ class MaskStager:
         self.device = torch.device(device)
         self.host, self.dev, self.events, self.turn = [None, None], [None, None], [None, None], 0
 
-    def stage(self, masks, G, out_h, out_w):
+    def stage(self, masks, G, out_h, out_w, via=None):
         """masks: list (per image) of uint8 [n_i, H, W] CPU tensors or None -> fp32 [B, G, out_h, out_w] on the device, or
-        None when the masks are not host uint8 maps of one size (the caller then takes the generic path)."""
+        None when the masks are not host uint8 maps of one size (the caller then takes the generic path). ``via`` = (Hv, Wv):
+        the batch size after the collate function's multiscale augmentation, which resizes the masks (nearest) once before
+        the criterion resizes them again -- pass it INSTEAD of resizing the masks on the host."""
         from . import _lib
 
         shapes = {tuple(m.shape[-2:]) for m in masks if m is not None and m.numel() > 0}
@@ -143,6 +145,72 @@ class MaskStager:
         self.events[slot] = ev
         out = torch.empty(B, G, out_h, out_w, dtype=torch.float32, device=self.device)
         lib = _lib.load()
-        rc = lib.dfine_mask_targets_nearest(_lib.ptr(dev), _lib.ptr(out), B * G, H, W, out_h, out_w, _lib.stream_ptr())
+        hv, wv = (int(via[0]), int(via[1])) if via is not None else (0, 0)
+        rc = lib.dfine_mask_targets_nearest(_lib.ptr(dev), _lib.ptr(out), B * G, H, W, hv, wv, out_h, out_w, _lib.stream_ptr())
         _lib.check(rc, "dfine_mask_targets_nearest")
         return out
+
+
+class ImageStager:
+    """Input staging of the images. The reference's loader normalises every image on the host
+    (A.Normalize + ToTensorV2, src/dl/dataset.py:128-131: uint8 HWC -> float32 CHW), stacks them, sometimes resizes the whole
+    float batch (multiscale, dataset.py:645-670) and then copies 4 bytes per value to the device. Here the decoded uint8 pixels go
+    into ONE pinned buffer [B, H, W, 3] (two, alternating, event-guarded like ``MaskStager``), cross PCIe at 1 byte per value,
+    and ONE kernel (dfine_stage_images) normalises, optionally resizes (PyTorch's bilinear rule) and writes the channels_last
+    tensor the stem reads."""
+
+    _instances = {}
+
+    @classmethod
+    def for_device(cls, device):
+        key = str(torch.device(device))
+        if key not in cls._instances:
+            cls._instances[key] = cls(device)
+        return cls._instances[key]
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.host, self.dev, self.events, self.turn = [None, None], [None, None], [None, None], 0
+
+    def stage(self, images, size=None, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), dtype=torch.float32):
+        """images: list of uint8 [H, W, 3] CPU tensors / numpy arrays of ONE size (or one [B, H, W, 3] tensor) ->
+        [B, 3, OH, OW] ``dtype`` (float32 or bfloat16) in channels_last memory on the device; ``size`` = (OH, OW) resizes."""
+        import ctypes
+
+        from . import _lib
+
+        if not isinstance(images, torch.Tensor):
+            images = [torch.as_tensor(im) for im in images]
+            if len({tuple(im.shape) for im in images}) != 1:
+                raise ValueError("ImageStager: the images of a batch must have one size (the loader letterboxes them)")
+            B, (H, W, C) = len(images), images[0].shape
+        else:
+            B, H, W, C = images.shape
+        if C != 3 or (images[0] if not isinstance(images, torch.Tensor) else images).dtype != torch.uint8:
+            raise ValueError("ImageStager: uint8 HWC images with 3 channels expected")
+        OH, OW = (int(size[0]), int(size[1])) if size is not None else (H, W)
+        slot = self.turn
+        self.turn ^= 1
+        n = B * H * W * 3
+        if self.host[slot] is None or self.host[slot].numel() < n:
+            self.host[slot] = torch.empty(n, dtype=torch.uint8).pin_memory()
+            self.dev[slot] = torch.empty(n, dtype=torch.uint8, device=self.device)
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()  # the transfer that last read this pinned buffer has finished
+        host = self.host[slot][:n].view(B, H, W, 3)
+        if isinstance(images, torch.Tensor):
+            host.copy_(images)
+        else:
+            for i, im in enumerate(images):
+                host[i].copy_(im)
+        dev = self.dev[slot][:n]
+        dev.copy_(self.host[slot][:n], non_blocking=True)
+        ev = self.events[slot] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.events[slot] = ev
+        out = torch.empty(B, OH, OW, 3, dtype=dtype, device=self.device)
+        lib = _lib.load()
+        m3, s3 = (ctypes.c_float * 3)(*[float(v) for v in mean]), (ctypes.c_float * 3)(*[float(v) for v in std])
+        rc = lib.dfine_stage_images(_lib.ptr(dev), _lib.ptr(out), _lib.dtype_code(out), B, H, W, OH, OW, m3, s3, _lib.stream_ptr())
+        _lib.check(rc, "dfine_stage_images")
+        return out.permute(0, 3, 1, 2)

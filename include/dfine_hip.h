@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 5
+#define DFINE_ABI_VERSION 6
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -456,10 +456,23 @@ int dfine_postprocess_masks(const void* probs, int dtype, const long long* qidx,
  * src/d_fine/dfine_criterion.py:239-270 _prepare_target_masks: per image m.float() -> F.interpolate(size=(Hm, Wm),
  * mode="nearest") -> clamp(0, 1)): masks u8 [n_maps, H, W] (n_maps = B*G padded slots, zero maps for padding)
  * -> out f32 [n_maps, Hm, Wm] in {0, 1}; source pixel = min(floor(dst * float(in)/float(out)), in - 1), bit-exact
- * with PyTorch's nearest rule.
+ * with PyTorch's nearest rule. (Hv, Wv) (0, 0 = H, W): the size the batch was resized to by the multiscale augmentation
+ * BEFORE the criterion (dataset.py:663-668 resizes the masks with mode="nearest" too): the two nearest maps are composed.
  * ------------------------------------------------------------------------------------- */
-int dfine_mask_targets_nearest(const unsigned char* masks, float* out, long long n_maps, int H, int W, int Hm, int Wm,
-                               void* stream);
+int dfine_mask_targets_nearest(const unsigned char* masks, float* out, long long n_maps, int H, int W, int Hv, int Wv, int Hm,
+                               int Wm, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Image staging (the step before the path): what the reference's data loader does on the host per image --
+ * A.Normalize(mean, std) + ToTensorV2 (src/dl/dataset.py:128-131), stacking, and the collate function's multiscale
+ * F.interpolate(images, size=(OH, OW), mode="bilinear", align_corners=False) (dataset.py:645-670) -- as ONE kernel over the
+ * packed uint8 batch:  src u8 [B, H, W, 3] (decoded pixels, HWC)  ->  dst f32 or bf16 [B, OH, OW, 3] (NHWC = the
+ * channels_last memory of a [B, 3, OH, OW] tensor, which is what the stem's implicit GEMM reads).
+ *   v = (u8 - mean_c*255) * (1 / (std_c*255)) in float32 (albumentations' arithmetic), then PyTorch's bilinear rule when
+ *   (OH, OW) != (H, W).  mean, std: HOST pointers to 3 floats each.
+ * ------------------------------------------------------------------------------------- */
+int dfine_stage_images(const unsigned char* src, void* dst, int dtype, int B, int H, int W, int OH, int OW,
+                       const float* mean, const float* std, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Deformable-attention backward split so that the value gradient needs no global atomics:

@@ -41,3 +41,55 @@ def test_pinned_double_buffer_is_not_overwritten_in_flight(hip_lib):
     torch.cuda.synchronize()
     for b, o in zip(batches, outs):
         assert torch.equal(o.cpu(), _ref(b, 4, 80, 80))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,size", [(64, 96, None), (64, 96, (128, 160)), (64, 96, (32, 64)), (37, 53, (96, 96)), (640, 640, (576, 576))])
+def test_image_staging_matches_normalize_then_interpolate(hip_lib, H, W, size):
+    """ImageStager vs the reference's host pipeline restated with plain PyTorch on the CPU: albumentations' A.Normalize
+    arithmetic ((u8 - mean*255) * float32(1 / (std*255))), ToTensorV2, stack, and the collate function's
+    F.interpolate(bilinear, align_corners=False). Unresized: bit-exact. Resized: within 2e-6 (values are O(1); the CPU
+    kernel and this one may contract the 4-tap sum differently). bf16 output = the fp32 result rounded once."""
+    from dfine_seg_amd.targets import ImageStager
+
+    g = torch.Generator().manual_seed(H + W)
+    imgs = [torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8) for _ in range(3)]
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    sub = torch.tensor(mean, dtype=torch.float32) * 255.0
+    mul = torch.reciprocal(torch.tensor(std, dtype=torch.float32) * 255.0)
+    ref = torch.stack([((im.float() - sub) * mul).permute(2, 0, 1) for im in imgs])
+    if size is not None:
+        ref = torch.nn.functional.interpolate(ref, size=size, mode="bilinear", align_corners=False)
+    st = ImageStager("cuda")
+    out = st.stage(imgs, size=size, mean=mean, std=std)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    if size is None:
+        assert torch.equal(out.cpu(), ref)
+    else:
+        assert float((out.cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    out16 = st.stage(imgs, size=size, mean=mean, std=std, dtype=torch.bfloat16)
+    assert float((out16.float().cpu() - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max()) + 2e-6
+    # the reference's default normalisation (mean 0, std 1): pixel / 255 as a reciprocal multiply
+    out01 = st.stage(torch.stack(imgs))
+    assert torch.equal(out01.cpu(), torch.stack([(im.float() * torch.reciprocal(torch.tensor(255.0))).permute(2, 0, 1) for im in imgs]))
+
+
+@pytest.mark.gpu
+def test_mask_targets_through_a_multiscale_resize(hip_lib):
+    """via=(Hv, Wv): the masks were NOT resized on the host; the kernel composes the collate function's nearest resize
+    (dataset.py:663-668) with the criterion's (dfine_criterion.py:239-270). Bit-exact."""
+    from dfine_seg_amd.targets import MaskStager
+
+    g = torch.Generator().manual_seed(3)
+    H, W, Hv, Wv, G = 64, 96, 128, 160, 5
+    masks = [(torch.rand(n, H, W, generator=g) > 0.5).to(torch.uint8) for n in (3, 0, 5)]
+    oh, ow = Hv // 4, Wv // 4
+    st = MaskStager("cuda")
+    got = st.stage(masks, G, oh, ow, via=(Hv, Wv)).cpu()
+    for i, m in enumerate(masks):
+        if m.shape[0] == 0:
+            assert float(got[i].abs().max()) == 0
+            continue
+        mid = (torch.nn.functional.interpolate(m.unsqueeze(1).float(), size=(Hv, Wv), mode="nearest").squeeze(1) > 0.5).to(torch.uint8)
+        ref = torch.nn.functional.interpolate(mid.unsqueeze(1).float(), size=(oh, ow), mode="nearest").squeeze(1).clamp(0, 1)
+        assert torch.equal(got[i, : m.shape[0]], ref)
