@@ -48,8 +48,8 @@ SIGNATURES = {
     "dfine_stage_images": [_c_void_p, _c_void_p] + [_c_int] * 6 + [_c_void_p] * 3,
     "dfine_postprocess_topk": [_c_void_p, _c_int] + [_c_void_p] * 6 + [_c_int] * 7 + [_c_void_p],
     "dfine_postprocess_masks": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_int] * 8 + [ctypes.c_float, _c_void_p],
-    "dfine_attention_fwd": [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p, _c_void_p, _c_int, _c_void_p] + [_c_int] * 4 + [ctypes.c_float, _c_void_p],
-    "dfine_attention_bwd": [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int,
+    "dfine_attention_fwd": [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p] + [_c_int] * 4 + [ctypes.c_float, _c_void_p],
+    "dfine_attention_bwd": [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int,
                             _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p] + [_c_int] * 4 + [ctypes.c_float, _c_void_p],
     "dfine_transpose_weights": [_c_void_p] * 4 + [_c_int, _c_void_p],
     "dfine_embedding_wgrad": [_c_void_p, _c_void_p, _c_int, _c_void_p, ctypes.c_longlong, _c_int, _c_int, _c_int, _c_void_p],
@@ -59,7 +59,7 @@ SIGNATURES = {
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int, _c_void_p, _c_int, _c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 IGEMM_MAX_TAPS = 16

@@ -275,7 +275,10 @@ class DFINETransformer(nn.Module):
             group = idx // (2 * max_gt)
             row_dn, col_dn = is_dn[:, None], is_dn[None, :]
             # matching queries cannot see denoising queries; a denoising group sees only itself (and the matching queries)
-            return (~row_dn & col_dn) | (row_dn & col_dn & (group[:, None] != group[None, :]))
+            blocked = (~row_dn & col_dn) | (row_dn & col_dn & (group[:, None] != group[None, :]))
+            if blocked.is_cuda:
+                blocked._attn_bits = ops.attention_mask_bits(blocked)  # packed once, next to the cached mask
+            return blocked
         return self._cached(("dn_mask", max_gt, groups, str(device)), make)
 
     # ---------------------------------------------------------------- denoising queries

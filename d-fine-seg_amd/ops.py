@@ -1299,6 +1299,20 @@ def conv_bias_act(x, conv, act=None, addend=None):
     return y
 
 
+def attention_mask_bits(blocked):
+    """bool [L, L] (True = may not attend) -> (bits_q, bits_k), int64 [L, ceil(L / 64)] each: the mask packed into 64-bit
+    words along the key axis (bits_q[q][t] bit j = blocked[q][64 t + j]) and along the query axis (bits_k[k][t] bit j =
+    blocked[64 t + j][k]) -- what dfine_attention_fwd / _bwd read instead of single bytes. A mask that is reused (the
+    decoder's denoising mask, cached per GT count) keeps the pair in its ``_attn_bits`` attribute."""
+    L = blocked.shape[0]
+    n_t = (L + 63) // 64
+    pad = torch.zeros(n_t * 64, n_t * 64, dtype=torch.bool, device=blocked.device)
+    pad[:L, :L] = blocked
+    weights = torch.ones(64, dtype=torch.int64, device=blocked.device) << torch.arange(64, device=blocked.device)  # bit 63 wraps: fine
+    pack = lambda m: (m.view(n_t * 64, n_t, 64).to(torch.int64) * weights).sum(-1)[:L].contiguous()
+    return pack(pad), pack(pad.t().contiguous())
+
+
 class _SelfAttention(torch.autograd.Function):
     """softmax(scale * Q K^T + mask) V on the projections' own layout; see include/dfine_hip.h (dfine_attention_*)."""
 
@@ -1312,20 +1326,24 @@ class _SelfAttention(torch.autograd.Function):
         qk, v = qk.contiguous(), v.contiguous()
         k_view = qk[..., D:]
         mask = blocked.view(torch.uint8).contiguous() if blocked is not None else None
+        bits_q = bits_k = None
+        if blocked is not None:
+            bits = getattr(blocked, "_attn_bits", None)
+            bits_q, bits_k = bits if bits is not None else attention_mask_bits(blocked)
         o = torch.empty(B, L, D, dtype=torch.bfloat16, device=qk.device)
         lse = torch.empty(B, n_head, L, dtype=torch.float32, device=qk.device)
         scale = 1.0 / dh ** 0.5
         with _lib.timed("attention_fwd", (3 * B * L * D + B * L * D) * 2, f"B{B} L{L} H{n_head} dh{dh}"):
-            rc = lib.dfine_attention_fwd(_lib.ptr(qk), _lib.ptr(k_view), _lib.ptr(v), D2, D2, D, _lib.ptr(mask), _lib.ptr(o), D,
-                                         _lib.ptr(lse), B, n_head, L, dh, scale, _lib.stream_ptr())
+            rc = lib.dfine_attention_fwd(_lib.ptr(qk), _lib.ptr(k_view), _lib.ptr(v), D2, D2, D, _lib.ptr(mask), _lib.ptr(bits_q),
+                                         _lib.ptr(o), D, _lib.ptr(lse), B, n_head, L, dh, scale, _lib.stream_ptr())
         _lib.check(rc, "dfine_attention_fwd")
-        ctx.save_for_backward(qk, v, o, lse, mask)
+        ctx.save_for_backward(qk, v, o, lse, mask, bits_q, bits_k)
         ctx.meta = (n_head, scale)
         return o
 
     @staticmethod
     def backward(ctx, go):
-        qk, v, o, lse, mask = ctx.saved_tensors
+        qk, v, o, lse, mask, bits_q, bits_k = ctx.saved_tensors
         n_head, scale = ctx.meta
         lib = _lib.load()
         B, L, D2 = qk.shape
@@ -1336,8 +1354,8 @@ class _SelfAttention(torch.autograd.Function):
         dv = torch.empty_like(v)
         dsum = torch.empty_like(lse)
         with _lib.timed("attention_bwd", 8 * B * L * D * 2, f"B{B} L{L} H{n_head} dh{dh}"):
-            rc = lib.dfine_attention_bwd(_lib.ptr(qk), _lib.ptr(qk[..., D:]), _lib.ptr(v), D2, D2, D, _lib.ptr(mask), _lib.ptr(o), D,
-                                         _lib.ptr(lse), _lib.ptr(go), D, _lib.ptr(dqk), D2, _lib.ptr(dqk[..., D:]), D2, _lib.ptr(dv), D,
+            rc = lib.dfine_attention_bwd(_lib.ptr(qk), _lib.ptr(qk[..., D:]), _lib.ptr(v), D2, D2, D, _lib.ptr(mask), _lib.ptr(bits_q),
+                                         _lib.ptr(bits_k), _lib.ptr(o), D, _lib.ptr(lse), _lib.ptr(go), D, _lib.ptr(dqk), D2, _lib.ptr(dqk[..., D:]), D2, _lib.ptr(dv), D,
                                          _lib.ptr(dsum), B, n_head, L, dh, scale, _lib.stream_ptr())
         _lib.check(rc, "dfine_attention_bwd")
         return dqk, dv, None, None

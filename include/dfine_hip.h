@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 6
+#define DFINE_ABI_VERSION 7
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -421,14 +421,19 @@ int dfine_embedding_wgrad(const long long* idx, const void* g, int dtype, float*
  * Backward: dout bf16 pitch lddo -> dq, dk, dv bf16 with their own pitches (dq / dk may be the halves of one
  *   [B*L, 2D] buffer), all written; dsum f32 [B, H, L] is scratch (rowsum(dO * O)). No atomics: results are
  *   bitwise reproducible.
+  *   bits_q / bits_k (optional, both or neither in the backward; used only together with `blocked`): the SAME mask packed
+ *   into 64-bit words, [L][ceil(L/64)] each -- bits_q[q][t] bit j = blocked[q][64t + j], bits_k[k][t] bit j =
+ *   blocked[64t + j][k] (bits beyond L are ignored). With them a lane reads one word per 64-row tile instead of 16 single
+ *   bytes; the byte path doubles the time of a masked launch (tools/time_attention.py).
  * ------------------------------------------------------------------------------------- */
 int dfine_attention_fwd(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
-                        const unsigned char* blocked, void* o, int ldo, float* lse, int B, int H, int L, int dh,
-                        float scale, void* stream);
+                        const unsigned char* blocked, const unsigned long long* bits_q, void* o, int ldo, float* lse,
+                        int B, int H, int L, int dh, float scale, void* stream);
 int dfine_attention_bwd(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv,
-                        const unsigned char* blocked, const void* o, int ldo, const float* lse, const void* dout,
-                        int lddo, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, float* dsum, int B,
-                        int H, int L, int dh, float scale, void* stream);
+                        const unsigned char* blocked, const unsigned long long* bits_q, const unsigned long long* bits_k,
+                        const void* o, int ldo, const float* lse, const void* dout, int lddo, void* dq, int lddq,
+                        void* dk, int lddk, void* dv, int lddv, float* dsum, int B, int H, int L, int dh, float scale,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Evaluation post-processing (reference src/dl/train.py:227-319 Trainer.preds_postprocess with

@@ -108,3 +108,47 @@ def test_reproducible_bit_for_bit(hip_lib):
         res.append((o.detach().clone(), a.grad.clone(), b.grad.clone()))
     for x, y in zip(*res):
         assert torch.equal(x, y)
+
+
+def test_packed_mask_equals_byte_mask(hip_lib):
+    """The kernels read the mask bit-packed (one 64-bit word per lane and 64-row tile); with bits_q / bits_k = NULL they read
+    `blocked` byte by byte. Same arithmetic: forward output, log-sum-exp and all three gradients must be BIT-equal, in the
+    tiled and in the whole-sequence-resident builds. The packing itself is checked against an explicit bit loop."""
+    from dfine_seg_amd import _lib, ops
+
+    torch.manual_seed(5)
+    B, L, H, dh = 2, 205, 4, 32  # ragged: 4 tiles, the last one 13 rows
+    D = H * dh
+    blocked = (torch.rand(L, L, device="cuda") < 0.3)
+    blocked[7] = True  # a fully blocked row
+    bits_q, bits_k = ops.attention_mask_bits(blocked)
+    bq, bk, bl = bits_q.cpu(), bits_k.cpu(), blocked.cpu()
+    for q in (0, 7, 63, 64, 204):
+        for kk in (0, 1, 63, 64, 128, 204):
+            assert bool((int(bq[q, kk // 64]) >> (kk % 64)) & 1) == bool(bl[q, kk])
+            assert bool((int(bk[kk, q // 64]) >> (q % 64)) & 1) == bool(bl[q, kk])
+    qk = torch.randn(B, L, 2 * D, device="cuda").bfloat16()
+    v = torch.randn(B, L, D, device="cuda").bfloat16()
+    go = torch.randn(B, L, D, device="cuda").bfloat16()
+    mask = blocked.view(torch.uint8).contiguous()
+    scale = 1.0 / dh ** 0.5
+
+    def run(with_bits):
+        o = torch.empty(B, L, D, dtype=torch.bfloat16, device="cuda")
+        lse = torch.empty(B, H, L, dtype=torch.float32, device="cuda")
+        dqk, dv, dsum = torch.empty_like(qk), torch.empty_like(v), torch.empty_like(lse)
+        pq, pk = (_lib.ptr(bits_q), _lib.ptr(bits_k)) if with_bits else (None, None)
+        rc = hip_lib.dfine_attention_fwd(_lib.ptr(qk), _lib.ptr(qk[..., D:]), _lib.ptr(v), 2 * D, 2 * D, D, _lib.ptr(mask), pq, _lib.ptr(o), D,
+                                         _lib.ptr(lse), B, H, L, dh, scale, _lib.stream_ptr())
+        assert rc == 0
+        rc = hip_lib.dfine_attention_bwd(_lib.ptr(qk), _lib.ptr(qk[..., D:]), _lib.ptr(v), 2 * D, 2 * D, D, _lib.ptr(mask), pq, pk, _lib.ptr(o), D,
+                                         _lib.ptr(lse), _lib.ptr(go), D, _lib.ptr(dqk), 2 * D, _lib.ptr(dqk[..., D:]), 2 * D, _lib.ptr(dv), D,
+                                         _lib.ptr(dsum), B, H, L, dh, scale, _lib.stream_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        return o, lse, dqk, dv
+
+    a, b = run(False), run(True)
+    for x, y, name in zip(a, b, ("o", "lse", "dqk", "dv")):
+        assert torch.equal(x, y), name
+    assert float(a[0][:, 7].float().abs().max()) == 0.0  # the blocked row
