@@ -81,6 +81,8 @@ __device__ __forceinline__ float giou_loss_grad(const float4 pb, const Box& p, c
   return 1.f - giou;
 }
 
+constexpr int CRIT_TERM_REPLICAS = 64;  // terms: f32 [64][8], columns 0..4 used
+
 template <typename T>
 __global__ __launch_bounds__(256) void criterion_head_kernel(
     const T* __restrict__ logits, const float* __restrict__ boxes, const float* __restrict__ corners,
@@ -209,8 +211,10 @@ __global__ __launch_bounds__(256) void criterion_head_kernel(
   }
   __syncthreads();
   if (threadIdx.x < 5) {
+    // 64 replicas of the five sums (the caller adds them up): ~4 000 workgroups adding into the SAME five floats -- one
+    // cache line, one L2 atomic unit -- serialised for ~40 us of this 52 us kernel
     const int k = threadIdx.x;
-    atomicAdd(terms + k, part[0][k] + part[1][k] + part[2][k] + part[3][k]);
+    atomicAdd(terms + (blockIdx.x % CRIT_TERM_REPLICAS) * 8 + k, part[0][k] + part[1][k] + part[2][k] + part[3][k]);
   }
 }
 

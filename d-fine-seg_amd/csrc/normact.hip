@@ -288,6 +288,11 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
   const int cbase = blockIdx.y * lanes;
   const int tid = threadIdx.y * blockDim.x + threadIdx.x;
   const float inv_n = 1.f / (float)g.n_pix;
+  // d lab_scale / d lab_bias are sums over ALL channels: the channels of this block are added up in LDS first (the global
+  // adds of a 128..1536-channel map all hit the same two floats and would serialise behind workgroup 0 otherwise)
+  __shared__ float lab_part[2];
+  if (tid < 2) lab_part[tid] = 0.f;
+  __syncthreads();
   for (int k = tid; k < lanes; k += blockDim.x * blockDim.y) {
     const int c = cbase + k;
     double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
@@ -307,12 +312,13 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
       dgamma[c] += s_dzx;
       dbeta[c] += s_dz;
       if (g.has_lab) {
-        atomicAdd(dlab_scale, (float)r2);
-        atomicAdd(dlab_bias, (float)r3);
+        atomicAdd(&lab_part[0], (float)r2);
+        atomicAdd(&lab_part[1], (float)r3);
       }
     }
   }
   __syncthreads();
+  if (blockIdx.x == 0 && g.has_lab && tid < 2) atomicAdd(tid == 0 ? dlab_scale : dlab_bias, lab_part[tid]);
   const int c0 = cbase + threadIdx.x * VEC;
   float mean[VEC], rstd[VEC], gam[VEC], bet[VEC], m_dz[VEC], m_dzx[VEC];
 #pragma unroll

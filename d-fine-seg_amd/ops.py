@@ -653,7 +653,7 @@ class _CriterionHead(torch.autograd.Function):
         if has_ddf:
             teacher_corners = teacher_corners.float().contiguous()
             teacher_logits = teacher_logits.to(logits.dtype).contiguous()
-        terms = zeros_f32(5, dev)
+        terms = zeros_f32(64 * 8, dev)  # 64 replicas of the five sums (see dfine_criterion_head)
         d_logits = torch.empty_like(logits)
         d_l1 = torch.empty(B, Q, 4, dtype=torch.float32, device=dev)
         d_giou = torch.empty_like(d_l1)
@@ -669,7 +669,7 @@ class _CriterionHead(torch.autograd.Function):
         _lib.check(rc, "dfine_criterion_head")
         ctx.save_for_backward(d_logits, d_l1, d_giou, d_fgl, d_ddf)
         ctx.mark_non_differentiable()
-        return tuple(terms.unbind(0))
+        return tuple(terms.view(64, 8)[:, :5].sum(0).unbind(0))
 
     @staticmethod
     def backward(ctx, g_vfl, g_l1, g_giou, g_fgl, g_ddf):

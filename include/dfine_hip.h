@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 7
+#define DFINE_ABI_VERSION 8
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -202,7 +202,9 @@ int dfine_adamw_ema_step(float* param, float* grad, float* exp_avg, float* exp_a
  *   tgt_labels [B,G] int64, tgt_boxes [B,G,4] f32, Wn [n_bins] f32 = W(n)
  *   scalars f32 [9] (device): 1/num_boxes (vfl), 1/num_boxes (boxes, FGL), DDF coefficient of a matched
  *       edge, of an unmatched edge, then the 5 loss weights (vfl, bbox, giou, fgl, ddf)
- *   terms f32 [5]: weighted loss_vfl, loss_bbox, loss_giou, loss_fgl, loss_ddf -- ACCUMULATED (caller zeroes)
+ *   terms f32 [64][8]: 64 replicas (workgroup b adds into replica b % 64: thousands of workgroups adding into the same
+ *       five floats serialise) of the weighted loss_vfl, loss_bbox, loss_giou, loss_fgl, loss_ddf in columns 0..4 --
+ *       ACCUMULATED (caller zeroes, and sums the replicas)
  *   d_logits [B,Q,C] (logits dtype), d_boxes_l1 / d_boxes_giou [B,Q,4], d_corners_fgl / d_corners_ddf
  *       [B,Q,4*n_bins] f32: gradient of the corresponding weighted term (overwritten)
  * ------------------------------------------------------------------------------------- */
