@@ -33,6 +33,8 @@ SIGNATURES = {
     "dfine_conv_wgrad": [_c_void_p] * 3 + [_c_int] * 13 + [_c_void_p],
     "dfine_fdr_head_fwd": [_c_void_p] * 6 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, _c_void_p],
     "dfine_fdr_head_bwd": [_c_void_p] * 7 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, _c_void_p],
+    "dfine_upsample2x_fwd": [_c_void_p, _c_int, _c_void_p] + [_c_int] * 5 + [_c_void_p],
+    "dfine_upsample2x_bwd": [_c_void_p, _c_int, _c_int, _c_void_p] + [_c_int] * 4 + [_c_void_p],
     "dfine_stem_pool_fwd": [_c_void_p, _c_int, _c_void_p] + [_c_int] * 5 + [_c_void_p],
     "dfine_stem_pool_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p] + [_c_int] * 4 + [_c_void_p],
     "dfine_mask_loss_stats": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_int] * 4 + [_c_void_p],
@@ -59,7 +61,7 @@ SIGNATURES = {
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int, _c_void_p, _c_int, _c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lib = None
 
 IGEMM_MAX_TAPS = 16

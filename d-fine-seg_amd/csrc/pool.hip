@@ -99,6 +99,67 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, 
   store_vec<T, V>(gx + (((size_t)b * H + yy) * W + xx) * C + c0, acc);
 }
 
+// Nearest x2 upsampling of the FPN (reference hybrid_encoder.py:377 F.interpolate(scale_factor=2., mode="nearest")), forward with
+// an output pitch -- the upsampled map is written straight into its half of the FPN concat buffer -- and backward (each input
+// pixel sums its 2x2 output gradients, read with a pitch from the buffer's gradient).
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C,
+                                                            int ldy) {
+  constexpr int V = VecTraits<T>::kElems;
+  const int cpp = C / V;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)B * 2 * H * 2 * W * cpp) return;
+  const int c0 = (int)(t % cpp) * V;
+  size_t p = t / cpp;
+  const int ox = (int)(p % (2 * W));
+  p /= 2 * W;
+  const int oy = (int)(p % (2 * H)), b = (int)(p / (2 * H));
+  const Vec16 v = *reinterpret_cast<const Vec16*>(x + (((size_t)b * H + (oy >> 1)) * W + (ox >> 1)) * C + c0);
+  *reinterpret_cast<Vec16*>(y + (((size_t)b * 2 * H + oy) * 2 * W + ox) * ldy + c0) = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int B, int H, int W, int C,
+                                                            int ld_gy) {
+  constexpr int V = VecTraits<T>::kElems;
+  const int cpp = C / V;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)B * H * W * cpp) return;
+  const int c0 = (int)(t % cpp) * V;
+  size_t p = t / cpp;
+  const int xx = (int)(p % W);
+  p /= W;
+  const int yy = (int)(p % H), b = (int)(p / H);
+  float acc[V], g[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      load_vec<T, V>(gy + (((size_t)b * 2 * H + 2 * yy + dy) * 2 * W + 2 * xx + dx) * ld_gy + c0, g);
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc[i] += g[i];
+    }
+  store_vec<T, V>(gx + (((size_t)b * H + yy) * W + xx) * C + c0, acc);
+}
+
+template <typename T>
+static int launch_upsample(bool fwd, const void* in, void* out, int B, int H, int W, int C, int ld, hipStream_t st) {
+  constexpr int V = VecTraits<T>::kElems;
+  if (C % V != 0) return DFINE_E_UNSUPPORTED;
+  if (ld == 0) ld = C;
+  if (ld < C) return DFINE_E_BADARG;
+  if (ld % V != 0 || (uintptr_t)(fwd ? out : in) % (V * sizeof(T)) != 0) return DFINE_E_UNSUPPORTED;
+  const size_t items = (size_t)B * H * W * (C / V) * (fwd ? 4 : 1);
+  const size_t blocks = (items + 255) / 256;
+  if (blocks > 0x7fffffffULL) return DFINE_E_UNSUPPORTED;
+  if (fwd) hipLaunchKernelGGL(upsample2x_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)in, (T*)out, B, H, W, C, ld);
+  else hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)in, (T*)out, B, H, W, C, ld);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T>
 static int launch_pool(bool fwd, const void* x, const void* gy, void* out, int B, int H, int W, int C, int ld, hipStream_t st) {
   constexpr int V = VecTraits<T>::kElems;
@@ -133,5 +194,21 @@ extern "C" int dfine_stem_pool_bwd(const void* x, const void* gy, int ld_gy, int
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return DFINE_E_BADARG;
   if (dtype == DFINE_DT_F32) return launch_pool<float>(false, x, gy, gx, B, H, W, C, ld_gy, (hipStream_t)stream);
   if (dtype == DFINE_DT_BF16) return launch_pool<bf16_t>(false, x, gy, gx, B, H, W, C, ld_gy, (hipStream_t)stream);
+  return DFINE_E_UNSUPPORTED;
+}
+
+extern "C" int dfine_upsample2x_fwd(const void* x, int dtype, void* y, int B, int H, int W, int C, int ldy, void* stream) {
+  if (!x || !y) return DFINE_E_BADARG;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return DFINE_E_BADARG;
+  if (dtype == DFINE_DT_F32) return launch_upsample<float>(true, x, y, B, H, W, C, ldy, (hipStream_t)stream);
+  if (dtype == DFINE_DT_BF16) return launch_upsample<bf16_t>(true, x, y, B, H, W, C, ldy, (hipStream_t)stream);
+  return DFINE_E_UNSUPPORTED;
+}
+
+extern "C" int dfine_upsample2x_bwd(const void* gy, int ld_gy, int dtype, void* gx, int B, int H, int W, int C, void* stream) {
+  if (!gy || !gx) return DFINE_E_BADARG;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return DFINE_E_BADARG;
+  if (dtype == DFINE_DT_F32) return launch_upsample<float>(false, gy, gx, B, H, W, C, ld_gy, (hipStream_t)stream);
+  if (dtype == DFINE_DT_BF16) return launch_upsample<bf16_t>(false, gy, gx, B, H, W, C, ld_gy, (hipStream_t)stream);
   return DFINE_E_UNSUPPORTED;
 }

@@ -147,7 +147,16 @@ class HybridEncoder(nn.Module):
 
     def forward(self, feats):
         """feats: backbone maps, fine to coarse -> (outs, inner_outs), both fine to coarse."""
-        proj = [p(f) for p, f in zip(self.input_proj, feats)]
+        from . import ops
+
+        # FPN / PAN concats without torch.cat (ops.ConcatBuffer): the upsampled map, the lateral input projection and the
+        # PAN's downsampled map are WRITTEN into their halves of the block's input buffer by the kernels that produce them
+        # (the stock cat of a channels_last and an NCHW-dense operand also cost a layout-conversion copy each way)
+        buffered = self.training and ops.concat_buffer_supported(feats[-1], [self.hidden, self.hidden])
+        proj = [None] * len(feats)
+        proj[-1] = self.input_proj[-1](feats[-1])
+        if not buffered:
+            proj = [p(f) for p, f in zip(self.input_proj, feats)]
         x = proj[-1]
         B, C, h, w = x.shape
         tokens = x.flatten(2).transpose(1, 2)  # a view for channel-last maps
@@ -158,10 +167,26 @@ class HybridEncoder(nn.Module):
         for lvl in range(len(proj) - 1, 0, -1):
             j = len(proj) - 1 - lvl
             inner[0] = self.lateral_convs[j](inner[0])
+            if buffered and ops.upsample_nearest2x_supported(inner[0]):
+                Bn, _, hh, ww = inner[0].shape
+                buf = ops.ConcatBuffer(Bn, 2 * hh, 2 * ww, 2 * self.hidden, torch.bfloat16, inner[0].device)
+                up = ops.upsample_nearest2x(inner[0], into=buf)
+                proj[lvl - 1] = self.input_proj[lvl - 1](feats[lvl - 1], into=buf)  # computed here, into the buffer's second half
+                inner.insert(0, self.fpn_blocks[j](ops.concat_read(buf, [up, proj[lvl - 1]])))
+                continue
+            if proj[lvl - 1] is None:
+                proj[lvl - 1] = self.input_proj[lvl - 1](feats[lvl - 1])
             up = F.interpolate(inner[0], scale_factor=2.0, mode="nearest")
             inner.insert(0, self.fpn_blocks[j](torch.cat([up, proj[lvl - 1]], 1)))
         outs = [inner[0]]
         for lvl in range(len(proj) - 1):
+            if buffered:
+                Bn, _, hh, ww = inner[lvl + 1].shape
+                buf = ops.ConcatBuffer(Bn, hh, ww, 2 * self.hidden, torch.bfloat16, inner[lvl + 1].device)
+                sc = self.downsample_convs[lvl][0]
+                down = sc.cv2(sc.cv1(outs[-1]), into=buf)
+                outs.append(self.pan_blocks[lvl](ops.concat_read(buf, [down, ops.concat_copy_in(inner[lvl + 1], buf)])))
+                continue
             down = self.downsample_convs[lvl](outs[-1])
             outs.append(self.pan_blocks[lvl](torch.cat([down, inner[lvl + 1]], 1)))
         return outs, inner

@@ -458,7 +458,9 @@ class _ConcatCopyIn(torch.autograd.Function):
     def forward(ctx, x, buffer, c0):
         C = x.shape[1]
         dst = buffer.buf[..., c0 : c0 + C]
-        dst.copy_(x.permute(0, 2, 3, 1))
+        # through .data: slices other producers already returned are autograd-visible views of the same base, and an in-place
+        # write that bumps ITS version would make autograd reject them (the slices are disjoint; ordering is ours to keep)
+        buffer.buf.data[..., c0 : c0 + C].copy_(x.permute(0, 2, 3, 1))
         ctx.slot = (buffer, c0, C)
         ctx.set_materialize_grads(False)
         return dst.permute(0, 3, 1, 2)
@@ -743,6 +745,57 @@ def stem_pool(x, into=None):
     [B, C, H, W] -> [B, C, H, W] (HGNetv2 stem, hgnetv2.py:213-224), HIP, no padded copy. ``into`` (a ConcatBuffer): the
     result becomes the buffer's next channel slice."""
     return _StemPool.apply(x, (into, into.take(x.shape[1])) if into is not None else None)
+
+
+class _Upsample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slot):
+        _lib.require_gpu(x)
+        lib = _lib.load()
+        xl = _nhwc(x)
+        B, H, W, C = xl.shape
+        ldy = 0
+        if slot is not None:
+            y = slot[0].buf[..., slot[1] : slot[1] + C]
+            ldy = slot[0].buf.shape[-1]
+            if y.dtype != xl.dtype or tuple(y.shape) != (B, 2 * H, 2 * W, C):
+                raise _lib.DfineHipError("upsample_nearest2x: the concat slot does not match the output")
+        else:
+            y = torch.empty(B, 2 * H, 2 * W, C, dtype=xl.dtype, device=xl.device)
+        with _lib.timed("upsample2x_fwd", 5 * xl.numel() * xl.element_size()):
+            rc = lib.dfine_upsample2x_fwd(_lib.ptr(xl), _lib.dtype_code(xl), _lib.ptr(y), B, H, W, C, ldy, _lib.stream_ptr())
+        _lib.check(rc, "dfine_upsample2x_fwd")
+        ctx.meta = (B, H, W, C, xl.dtype, slot)
+        ctx.set_materialize_grads(False)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, H, W, C, dtype, slot = ctx.meta
+        lib = _lib.load()
+        if slot is not None and slot[0].grad is not None:
+            g2 = slot[0].grad[..., slot[1] : slot[1] + C].to(dtype)
+            gy = g2 if gy is None else g2 + gy.permute(0, 2, 3, 1)
+        elif gy is None:
+            return None, None
+        else:
+            gy = gy.to(dtype).permute(0, 2, 3, 1)
+        gyl, ld = _grad_rows(gy, C)
+        gx = torch.empty(B, H, W, C, dtype=dtype, device=gyl.device)
+        with _lib.timed("upsample2x_bwd", 5 * gx.numel() * gx.element_size()):
+            rc = lib.dfine_upsample2x_bwd(_lib.ptr(gyl), ld, _lib.dtype_code(gx), _lib.ptr(gx), B, H, W, C, _lib.stream_ptr())
+        _lib.check(rc, "dfine_upsample2x_bwd")
+        return gx.permute(0, 3, 1, 2), None
+
+
+def upsample_nearest2x(x, into=None):
+    """``F.interpolate(x, scale_factor=2., mode="nearest")`` on a channels_last map (the FPN's upsampling,
+    hybrid_encoder.py:377); ``into`` (a ConcatBuffer): the result becomes the buffer's next channel slice."""
+    return _Upsample2x.apply(x, (into, into.take(x.shape[1])) if into is not None else None)
+
+
+def upsample_nearest2x_supported(x):
+    return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0
 
 
 def stem_pool_supported(x):
@@ -1116,7 +1169,7 @@ class _Linear(torch.autograd.Function):
         N, K = r1 - r0, weight.shape[1]
         gy16 = gy.to(torch.bfloat16).reshape(-1, N)
         if relu:
-            gy16 = gy16 * (y > 0)
+            gy16 = torch.ops.aten.threshold_backward(gy16, y.reshape(-1, N), 0)  # one launch instead of compare + multiply
         if not gy16.is_contiguous():
             gy16 = gy16.contiguous()
         M = x2.shape[0]

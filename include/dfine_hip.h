@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 8
+#define DFINE_ABI_VERSION 9
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -311,6 +311,17 @@ int dfine_fdr_head_bwd(const float* corners, const float* ref_boxes, const float
 int dfine_stem_pool_fwd(const void* x, int dtype, void* y, int B, int H, int W, int C, int ldy, void* stream);
 int dfine_stem_pool_bwd(const void* x, const void* gy, int ld_gy, int dtype, void* gx, int B, int H, int W, int C,
                         void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Nearest-neighbour x2 upsampling of the encoder's FPN (reference src/d_fine/arch/hybrid_encoder.py:377
+ * F.interpolate(feat_high, scale_factor=2., mode="nearest")) on a channels_last map, forward and backward:
+ *     y[b, 2h+i, 2w+j, :] = x[b, h, w, :]            gx[b, h, w, :] = sum_{i,j in {0,1}} gy[b, 2h+i, 2w+j, :]
+ *   x, gx [B, H, W, C]; y, gy [B, 2H, 2W, C] with pixel pitch ldy / ld_gy (elements, 0 = C): the upsampled map is one half of the
+ *   FPN block's concat buffer (hybrid_encoder.py:378 torch.cat([upsample_feat, feat_low], dim=1) disappears). C a multiple of
+ *   the 16-byte vector; pitched operand 16-byte aligned.
+ * ------------------------------------------------------------------------------------- */
+int dfine_upsample2x_fwd(const void* x, int dtype, void* y, int B, int H, int W, int C, int ldy, void* stream);
+int dfine_upsample2x_bwd(const void* gy, int ld_gy, int dtype, void* gx, int B, int H, int W, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Mask loss of the matched queries (reference src/d_fine/dfine_criterion.py:272-357: _focal_loss_mask,

@@ -15,19 +15,35 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     t.step(images, targets)
     torch.cuda.synchronize()
+# backward ops carry no Python stack: label them with the autograd node that was being evaluated when they were launched
+evs = list(prof.events())
+nodes = sorted(((e.time_range.start, e.time_range.end, e.name.split(": ", 1)[-1], e.thread) for e in evs
+                if e.name.startswith("autograd::engine::evaluate_function")), key=lambda t: t[0])
+import bisect
+starts = [n[0] for n in nodes]
+def node_of(e):
+    i = bisect.bisect_right(starts, e.time_range.start) - 1
+    while i >= 0 and i > bisect.bisect_right(starts, e.time_range.start) - 50:
+        s0, e0, name, th = nodes[i]
+        if s0 <= e.time_range.start and e.time_range.end <= e0 and th == e.thread:
+            return name
+        i -= 1
+    return None
 agg = collections.defaultdict(lambda: [0.0, 0])
-for ev in prof.events():
+for ev in evs:
     if not ev.name.startswith("aten::") or ev.self_device_time_total <= 0:
         continue
-    site = "backward (autograd engine)"
-    for fr in ev.stack:
-        if "d-fine-seg_amd" in fr or "dfine_seg_amd" in fr:
-            site = fr.split("d-fine-seg_amd/")[-1].split("dfine_seg_amd/")[-1]
-            break
-    k = (ev.name, site, str(ev.input_shapes)[:90])
+    site = node_of(ev)
+    if site is None:
+        site = "forward"
+        for fr in ev.stack:
+            if "d-fine-seg_amd" in fr or "dfine_seg_amd" in fr:
+                site = "fwd " + fr.split("d-fine-seg_amd/")[-1].split("dfine_seg_amd/")[-1][:50]
+                break
+    k = (ev.name, site, str(ev.input_shapes)[:70])
     agg[k][0] += ev.self_device_time_total
     agg[k][1] += 1
 tot = sum(v[0] for v in agg.values())
 print(f"aten self device time {tot/1e3:.2f} ms")
-for (name, site, shapes), (us, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
-    print(f"{us/1e3:7.3f} ms n={n:3d} {name:28s} {site:60s} {shapes}")
+for (name, site, shapes), (us, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:90]:
+    print(f"{us/1e3:7.3f} ms n={n:3d} {name:26s} {site:44s} {shapes}")
