@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const bf16_t* __restrict_
   for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
   const int ncol = n0 + o_j * 8;
   const int nvalid = min(max(g.N - ncol, 0), 8);
+  const bool accumulate = (g.act & 0x400) != 0;
 #pragma unroll
   for (int i = 0; i < BM / ORPP; ++i) {
     const int ml = o_r + i * ORPP, m = m0 + ml;
@@ -284,7 +285,26 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const bf16_t* __restrict_
       orow = (size_t)m * g.ldc;
     }
     bf16_t* dst = C + orow + ncol;
-    if (OVEC == 8 && nvalid == 8) {
+    if (accumulate) {  // C += result: the second of two input gradients of one tensor (RepVgg's 3x3 + 1x1, CSP's two 1x1)
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      if (OVEC == 8 && nvalid == 8) {
+        const uint4 old = *reinterpret_cast<const uint4*>(dst);
+        const uint32_t o[4] = {old.x, old.y, old.z, old.w};
+        uint32_t r[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = __uint_as_float(w[q] << 16) + __uint_as_float(o[q] << 16);
+          const float hi = __uint_as_float(w[q] & 0xffff0000u) + __uint_as_float(o[q] & 0xffff0000u);
+          r[q] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+        }
+        *reinterpret_cast<uint4*>(dst) = make_uint4(r[0], r[1], r[2], r[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e < nvalid)
+            dst[e] = f32_to_bf16(__uint_as_float((w[e >> 1] >> (16 * (e & 1))) << 16) + bf16_to_f32(dst[e]));
+      }
+    } else if (OVEC == 8 && nvalid == 8) {
       *reinterpret_cast<uint4*>(dst) = v;
     } else {
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -392,7 +412,8 @@ extern "C" int dfine_igemm_bf16(const void* A, const void* Bw, void* C, const fl
   if (!A || !Bw || !C || !geom) return DFINE_E_BADARG;
   const IGemmGeom& g = *geom;
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.lda <= 0 || g.ldb < 0 || g.ldc < g.N) return DFINE_E_BADARG;
-  if ((g.act & 0xff) > 1) return DFINE_E_BADARG;  // bit 8: diagnostic, statistics computed but not published
+  if ((g.act & 0xff) > 1) return DFINE_E_BADARG;  // bits 8, 9: diagnostics of the statistics epilogue; bit 10: C += result
+  if ((g.act & 0x400) && stats) return DFINE_E_BADARG;
   long long a_extent;  // elements addressed in A (pixel offsets are 32-bit in the kernel)
   if (g.gather) {
     if (g.PH <= 0 || g.PW <= 0 || g.IH <= 0 || g.IW <= 0 || g.CI <= 0 || g.ntaps <= 0 || g.ntaps > DFINE_IGEMM_MAX_TAPS)

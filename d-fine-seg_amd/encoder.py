@@ -7,7 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .configs import ModelSpec
-from .layers import ConvNorm, LayerNorm, Linear, PackedSelfAttention
+from .layers import ConvNorm, conv_pair, LayerNorm, Linear, PackedSelfAttention
 
 
 class RepVgg(nn.Module):
@@ -40,7 +40,10 @@ class RepVgg(nn.Module):
             from . import ops
 
             return ops.conv_bias_act(x, self.conv, "silu")
-        return self.conv1(x, addend=self.conv2(x), act="silu")  # one fused norm+add+silu
+        if hasattr(self.conv1, "conv_bn_fused") or hasattr(self.conv2, "conv_bn_fused"):
+            return self.conv1(x, addend=self.conv2(x), act="silu")
+        (y3, ws3, hs3), (y1, ws1, hs1) = conv_pair(self.conv1, self.conv2, x)  # one input gradient for the two branches
+        return self.conv1._norm_tail(y3, ws3, hs3, addend=self.conv2._norm_tail(y1, ws1, hs1), act="silu")  # fused norm+add+silu
 
 
 class CSP(nn.Module):
@@ -54,7 +57,10 @@ class CSP(nn.Module):
         self.bottlenecks = nn.Sequential(*[RepVgg(c_out) for _ in range(n)])
 
     def forward(self, x):
-        return self.bottlenecks(self.conv1(x)) + self.conv2(x)
+        if hasattr(self.conv1, "conv_bn_fused") or hasattr(self.conv2, "conv_bn_fused"):
+            return self.bottlenecks(self.conv1(x)) + self.conv2(x)
+        (ya, ws_a, hs_a), (yb, ws_b, hs_b) = conv_pair(self.conv1, self.conv2, x)
+        return self.bottlenecks(self.conv1._norm_tail(ya, ws_a, hs_a)) + self.conv2._norm_tail(yb, ws_b, hs_b)
 
 
 class RepNCSPELAN4(nn.Module):

@@ -130,8 +130,9 @@ def conv_forward(x, w_khwc, stride=1, pad=0, pad_br=None, out=None, stats=None, 
     return out
 
 
-def conv_input_grad(gy, wt_ckhwk, in_hw, stride=1, pad=0, out=None):
-    """gy [B, OH, OW, CO] pixel rows, wt [CI, KH, KW, CO] dense bf16 (the transposed weight) -> dx [B, H, W, CI]."""
+def conv_input_grad(gy, wt_ckhwk, in_hw, stride=1, pad=0, out=None, accumulate=False):
+    """gy [B, OH, OW, CO] pixel rows, wt [CI, KH, KW, CO] dense bf16 (the transposed weight) -> dx [B, H, W, CI].
+    ``accumulate`` (stride 1, with ``out``): out += dx in the GEMM's epilogue."""
     _check_bf16(gy, wt_ckhwk)
     gy, lda = as_pixel_rows(gy)
     B, OH, OW, CO = gy.shape
@@ -143,8 +144,11 @@ def conv_input_grad(gy, wt_ckhwk, in_hw, stride=1, pad=0, out=None):
     if ldc is None or tuple(out.shape) != (B, H, W, CI):
         raise _lib.DfineHipError("conv_input_grad: output must be a [B, H, W, CI] pixel-row view")
     detail = f"dgrad {B}x{H}x{W} {CI}<-{CO} k{KH}s{stride}"
+    acc = 0x400 if accumulate else 0
+    if accumulate and stride != 1:
+        raise _lib.DfineHipError("conv_input_grad: accumulate is for stride-1 convolutions")
     if KH == 1 and KW == 1 and stride == 1 and pad == 0:
-        g = _geom(M=B * H * W, N=CI, K=CO, lda=lda, ldb=CO, ldc=ldc, gather=0)
+        g = _geom(M=B * H * W, N=CI, K=CO, lda=lda, ldb=CO, ldc=ldc, gather=0, act=acc)
         _launch(gy, wt_ckhwk, out, None, None, g, "conv_dgrad", detail)
         return out
     classes = []
@@ -161,7 +165,7 @@ def conv_input_grad(gy, wt_ckhwk, in_hw, stride=1, pad=0, out=None):
         if not taps or ph <= 0 or pw <= 0:
             continue
         g = _geom(M=B * ph * pw, N=CI, K=len(taps) * CO, lda=lda, ldb=KH * KW * CO, ldc=ldc, gather=1, PH=ph, PW=pw, IH=OH, IW=OW,
-                  CI=CO, isy=1, isx=1, OHf=H, OWf=W, osy=stride, osx=stride, ooy=ey, oox=ex, taps=taps)
+                  CI=CO, isy=1, isx=1, OHf=H, OWf=W, osy=stride, osx=stride, ooy=ey, oox=ex, taps=taps, act=acc)
         _launch(gy, wt_ckhwk, out, None, None, g, "conv_dgrad", detail)
     return out
 

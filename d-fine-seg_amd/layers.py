@@ -107,10 +107,29 @@ class ConvNorm(nn.Module):
         if hasattr(self, "conv_bn_fused"):  # deployed: conv + bias (+ activation)
             y = ops.conv_bias_act(x, self.conv_bn_fused, act if act is not None else self.act_name, addend)
             return self.lab(y) if hasattr(self, "lab") else y
+        y, ws, have_stats = self._conv(x)
+        return self._norm_tail(y, ws, have_stats, addend, act, slot)
+
+    def _pairable(self, x):
+        """This layer's conv can be one half of ops.dense_conv_pair: plain dense stride-1 conv on the bf16 GPU path."""
+        if hasattr(self, "conv_bn_fused"):
+            return False
         conv = self.conv
+        return (conv.groups == 1 and conv.stride == (1, 1) and conv.padding[0] == conv.padding[1] and isinstance(conv.padding[0], int)
+                and conv.dilation == (1, 1) and self.pad_br is None and x.is_cuda
+                and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16))
+
+    def _stats_workspace(self, x):
+        """(ws, have_stats): the norm's workspace when the conv's epilogue is to leave the batch statistics in it."""
         norm = getattr(self, self.norm_name)
-        frozen = isinstance(norm, FrozenBatchNorm2d)
-        batch_stats = self.training and not frozen
+        bf16_mode = x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16)
+        if bf16_mode and self.training and isinstance(norm, nn.BatchNorm2d):
+            return ops.bn_workspace(self.conv.out_channels, x.device), True
+        return None, False
+
+    def _conv(self, x):
+        """The convolution alone -> (output, norm workspace, whether the workspace already holds the batch statistics)."""
+        conv = self.conv
         ws, have_stats = None, False
         if conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1:
             x = ops.depthwise_conv2d(x, conv.weight, conv.stride[0])  # HIP: MIOpen has no fast path here
@@ -118,15 +137,21 @@ class ConvNorm(nn.Module):
               and isinstance(conv.padding[0], int) and conv.dilation == (1, 1)):
             # HIP implicit-GEMM forward / input gradient, HIP wgrad straight into the fp32 grads; in bf16 training mode
             # the conv's epilogue leaves the BatchNorm statistics in the norm's workspace (no statistics pass)
-            bf16_mode = x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16)
-            if bf16_mode and batch_stats and isinstance(norm, nn.BatchNorm2d):
-                ws, have_stats = ops.bn_workspace(conv.out_channels, x.device), True
+            ws, have_stats = self._stats_workspace(x)
             x = ops.dense_conv(x, conv.weight, conv.stride[0], conv.padding[0], self.pad_br,
                                stats=ws[: 32 * conv.out_channels] if have_stats else None)
         else:
             if self.pad_br is not None:
                 x = F.pad(x, (0, self.pad_br, 0, self.pad_br))
             x = conv(x)
+        return x, ws, have_stats
+
+    def _norm_tail(self, x, ws, have_stats, addend=None, act=None, slot=None):
+        """norm (+ addend) + activation (+ LAB) of a conv output."""
+        conv = self.conv
+        norm = getattr(self, self.norm_name)
+        frozen = isinstance(norm, FrozenBatchNorm2d)
+        batch_stats = self.training and not frozen
         act_name = act if act is not None else self.act_name
         lab = getattr(self, "lab", None)
         fused = (isinstance(norm, nn.BatchNorm2d) or frozen) and ops.batch_norm_act_supported(x, conv.out_channels)
@@ -156,6 +181,19 @@ class ConvNorm(nn.Module):
         if self._pending_batches and getattr(norm, "num_batches_tracked", None) is not None:
             norm.num_batches_tracked += self._pending_batches
         self._pending_batches = 0
+
+
+def conv_pair(a, b, x):
+    """The convolutions of two ConvNorm layers that read the SAME input (RepVgg's 3x3 + 1x1 branches, CSPLayer's two 1x1
+    projections) -> ((ya, ws_a, stats_a), (yb, ws_b, stats_b)) for their ``_norm_tail``. On the bf16 GPU path the pair is one
+    autograd node: its backward forms ONE input gradient, the second implicit GEMM adding into the first's output
+    (ops.dense_conv_pair) -- otherwise autograd sums the two with an extra kernel over the map."""
+    if a._pairable(x) and b._pairable(x) and torch.is_grad_enabled():
+        (ws_a, hs_a), (ws_b, hs_b) = a._stats_workspace(x), b._stats_workspace(x)
+        ya, yb = ops.dense_conv_pair(x, a.conv.weight, b.conv.weight, a.conv.padding[0], b.conv.padding[0],
+                                     ws_a[: 32 * a.conv.out_channels] if hs_a else None, ws_b[: 32 * b.conv.out_channels] if hs_b else None)
+        return (ya, ws_a, hs_a), (yb, ws_b, hs_b)
+    return a._conv(x), b._conv(x)
 
 
 def fuse_conv_norm(conv, norm):

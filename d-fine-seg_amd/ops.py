@@ -1266,30 +1266,99 @@ class _DenseConv(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = gemm.conv_input_grad(gyl, bf16_t_of(weight), (H, W), stride, padding).permute(0, 3, 1, 2)
-        gyc, xc = gyl, xl  # pixel rows of pitch ldy / ldx (channel slices are read in place)
-        ldy, ldx = gemm.pixel_pitch(gyc), gemm.pixel_pitch(xc)
-        taps = KH * KW
-        # the fp32 gradient must be laid out [K_out][KH][KW][C_in] (a channels_last weight's memory order)
-        direct = (DIRECT_WGRAD_ACCUM and weight.grad is not None and weight.grad.dtype == torch.float32
-                  and _is_khwc(weight.grad))
-        if direct:
-            dw = weight.grad
-        else:
-            dw = torch.zeros(K_out, C_in, KH, KW, dtype=torch.float32, device=xl.device).contiguous(memory_format=torch.channels_last)
-        M = B * OH * OW
-        nbytes, flops = (M * K_out + xc.numel()) * 2 + K_out * C_in * taps * 4, 2.0 * M * K_out * C_in * taps
-        if direct and wgrad_queue is not None:
-            prob = _lib.WgradProblem(dY=gyc.data_ptr(), X=xc.data_ptr(), dW=dw.data_ptr(), db=None, conv=1, B=B, H=H, W=W, CI=C_in,
-                                     OH=OH, OW=OW, CO=K_out, KH=KH, KW=KW, stride=stride, pad=padding, ldy=ldy, ldx=ldx)
-            if wgrad_queue.add(prob, (gyc, xc), nbytes, flops):
-                return dx, None, None, None, None, None, None
-        with on_wgrad_stream(gyc, xc) if direct else _NullCtx():
-            with _lib.timed("wgrad", nbytes,
-                            f"conv {B}x{H}x{W} {C_in}->{K_out} k{KH}s{stride}", flops=flops):
-                rc = lib.dfine_conv_wgrad(_lib.ptr(gyc), _lib.ptr(xc), _lib.ptr(dw), B, H, W, C_in, OH, OW, K_out, KH, KW,
-                                          stride, padding, ldy, ldx, _lib.stream_ptr())
-        _lib.check(rc, "dfine_conv_wgrad")
-        return dx, (None if direct else dw.to(weight.dtype)), None, None, None, None, None
+        dw = _conv_weight_grad(weight, gyl, xl, stride, padding)
+        return dx, dw, None, None, None, None, None
+
+
+def _conv_weight_grad(weight, gyc, xc, stride, padding):
+    """Weight gradient of a dense conv from its output gradient ``gyc`` and input ``xc`` (NHWC pixel rows, possibly channel
+    slices read in place): accumulated straight into the fp32 ``weight.grad`` -- queued for the grouped launch when a
+    WgradQueue is installed -- and ``None`` returned; or computed into a fresh tensor and returned for autograd."""
+    from . import gemm
+
+    lib = _lib.load()
+    K_out, C_in, KH, KW = weight.shape
+    B, H, W, _ = xc.shape
+    OH, OW = gyc.shape[1], gyc.shape[2]
+    ldy, ldx = gemm.pixel_pitch(gyc), gemm.pixel_pitch(xc)
+    taps = KH * KW
+    # the fp32 gradient must be laid out [K_out][KH][KW][C_in] (a channels_last weight's memory order)
+    direct = (DIRECT_WGRAD_ACCUM and weight.grad is not None and weight.grad.dtype == torch.float32
+              and _is_khwc(weight.grad))
+    if direct:
+        dw = weight.grad
+    else:
+        dw = torch.zeros(K_out, C_in, KH, KW, dtype=torch.float32, device=xc.device).contiguous(memory_format=torch.channels_last)
+    M = B * OH * OW
+    nbytes, flops = (M * K_out + xc.numel()) * 2 + K_out * C_in * taps * 4, 2.0 * M * K_out * C_in * taps
+    if direct and wgrad_queue is not None:
+        prob = _lib.WgradProblem(dY=gyc.data_ptr(), X=xc.data_ptr(), dW=dw.data_ptr(), db=None, conv=1, B=B, H=H, W=W, CI=C_in,
+                                 OH=OH, OW=OW, CO=K_out, KH=KH, KW=KW, stride=stride, pad=padding, ldy=ldy, ldx=ldx)
+        if wgrad_queue.add(prob, (gyc, xc), nbytes, flops):
+            return None
+    with on_wgrad_stream(gyc, xc) if direct else _NullCtx():
+        with _lib.timed("wgrad", nbytes,
+                        f"conv {B}x{H}x{W} {C_in}->{K_out} k{KH}s{stride}", flops=flops):
+            rc = lib.dfine_conv_wgrad(_lib.ptr(gyc), _lib.ptr(xc), _lib.ptr(dw), B, H, W, C_in, OH, OW, K_out, KH, KW,
+                                      stride, padding, ldy, ldx, _lib.stream_ptr())
+    _lib.check(rc, "dfine_conv_wgrad")
+    return None if direct else dw.to(weight.dtype)
+
+
+class _DenseConvPair(torch.autograd.Function):
+    """Two stride-1 dense convolutions of the SAME input (RepVgg's 3x3 + 1x1 branches, hybrid_encoder.py:106-121; CSPLayer's
+    conv1 / conv2, :209-239) as one autograd node: forward = two implicit GEMMs (each may leave its BatchNorm statistics),
+    backward = ONE input gradient -- the second GEMM adds into the first's output in its epilogue (dfine_igemm_bf16, act | 0x400)
+    instead of autograd summing two maps with an extra kernel -- and two (queued) weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, wa, wb, pad_a, pad_b, stats_a, stats_b):
+        from . import gemm
+
+        xl = gemm.nhwc(x.to(torch.bfloat16))
+        if gemm.pixel_pitch(xl) is None:
+            xl = xl.contiguous()
+        ya = gemm.conv_forward(xl, _khwc(bf16_of(wa)), 1, pad_a, None, stats=stats_a)
+        yb = gemm.conv_forward(xl, _khwc(bf16_of(wb)), 1, pad_b, None, stats=stats_b)
+        ctx.save_for_backward(xl)
+        ctx.meta = (wa, wb, pad_a, pad_b)
+        ctx.set_materialize_grads(False)
+        return ya.permute(0, 3, 1, 2), yb.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        from . import gemm
+
+        (xl,) = ctx.saved_tensors
+        wa, wb, pad_a, pad_b = ctx.meta
+        B, H, W, _ = xl.shape
+
+        def rows(g):
+            gl = gemm.nhwc(g.to(torch.bfloat16))
+            return gl if gemm.pixel_pitch(gl) is not None else gl.contiguous()
+
+        dx, dwa, dwb = None, None, None
+        for g, w, pad in ((ga, wa, pad_a), (gb, wb, pad_b)):
+            if g is None:
+                continue
+            gl = rows(g)
+            if ctx.needs_input_grad[0]:
+                if dx is None:
+                    dx = gemm.conv_input_grad(gl, bf16_t_of(w), (H, W), 1, pad)
+                else:
+                    gemm.conv_input_grad(gl, bf16_t_of(w), (H, W), 1, pad, out=dx, accumulate=True)
+            dw = _conv_weight_grad(w, gl, xl, 1, pad)
+            if w is wa:
+                dwa = dw
+            else:
+                dwb = dw
+        return (dx.permute(0, 3, 1, 2) if dx is not None else None), dwa, dwb, None, None, None, None
+
+
+def dense_conv_pair(x, weight_a, weight_b, pad_a, pad_b, stats_a=None, stats_b=None):
+    """(F.conv2d(x, weight_a, padding=pad_a), F.conv2d(x, weight_b, padding=pad_b)) for two stride-1 dense convs of one input,
+    bf16 GPU path (see _DenseConvPair). ``stats_*``: as in ``dense_conv``."""
+    return _DenseConvPair.apply(x, weight_a, weight_b, int(pad_a), int(pad_b), stats_a, stats_b)
 
 
 def _is_khwc(t):

@@ -380,7 +380,8 @@ int dfine_add_layernorm_bwd(const void* dy, const void* s, int dtype, const floa
  *   [CI][KH][KW][CO] (dfine_transpose_weights); a strided conv's input gradient is one launch per parity class of input
  *   pixels (osy/ooy select the class, only the taps of that class are listed); transposed 2x2 stride-2 conv: four
  *   1-tap launches with osy = osx = 2 and (ooy, oox) = the tap.
- *   A, Bw, C bf16; bias f32 [N] or NULL; act 0 = none, 1 = ReLU.
+ *   A, Bw, C bf16; bias f32 [N] or NULL; act 0 = none, 1 = ReLU; act | 0x400: C += result (bf16 sum of the stored C and the
+ *   rounded result -- what autograd's accumulation of two input gradients computes, without its add kernel; no `stats`).
  *   stats (or NULL): f64 [8][2][N], ACCUMULATED: per output channel the sum and the sum of squares of the bf16-rounded
  *   outputs, spread over 8 replicas -- the layout dfine_bn_act_fwd reads, so a BatchNorm after the conv skips its
  *   statistics pass. Any alignment is accepted (16-byte vector path when CI (gather) / K (plain), lda, ldb are

@@ -145,3 +145,34 @@ def test_full_size_linearity_property(hip_lib):
     torch.testing.assert_close(yab.float(), ya.float() + yb.float(), rtol=2 ** -7, atol=0.25)
     ref = F.conv2d(x1[:2].float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1)
     _close(ya[:2], ref, "full-size spot check")
+
+
+def test_two_convs_of_one_input_form_one_input_gradient(hip_lib, monkeypatch):
+    """ops.dense_conv_pair (RepVgg's 3x3 + 1x1, CSPLayer's two 1x1): the second input-gradient GEMM adds into the first's
+    output in its epilogue (dfine_igemm_bf16 act | 0x400). The sum it forms -- bf16(bf16 dx_a + bf16 dx_b) -- is what autograd's
+    accumulation computes from the two separate nodes: outputs and input gradient BIT-equal (weight gradients to the order of
+    their float atomics), on RepVgg and on a CSP block of the encoder."""
+    import copy
+
+    from dfine_seg_amd.encoder import CSP, RepVgg
+    from dfine_seg_amd.layers import ConvNorm
+
+    torch.manual_seed(0)
+    for make, x in ((lambda: RepVgg(64), torch.randn(3, 64, 20, 28, device="cuda")), (lambda: CSP(96, 64, 2), torch.randn(2, 96, 17, 23, device="cuda"))):
+        mod = make().cuda().to(memory_format=torch.channels_last).train()
+        ref = copy.deepcopy(mod)
+        x = x.bfloat16().contiguous(memory_format=torch.channels_last)
+        outs = []
+        for m, paired in ((ref, False), (mod, True)):
+            if not paired:
+                monkeypatch.setattr(ConvNorm, "_pairable", lambda self, x: False)
+            xx = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(xx)
+            (y.float() * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
+            outs.append((y.detach(), xx.grad, {n: p.grad for n, p in m.named_parameters()}))
+            monkeypatch.undo()
+        (y0, g0, p0), (y1, g1, p1) = outs
+        assert torch.equal(y0, y1) and torch.equal(g0, g1)
+        for n in p0:  # weight gradients are sums of float atomics (order varies run to run), the rest are plain reductions
+            torch.testing.assert_close(p0[n], p1[n], rtol=1e-4, atol=1e-4 * float(p0[n].abs().max()), msg=lambda m: f"{n}: {m}")

@@ -117,10 +117,12 @@ class _StockOps:
         from dfine_seg_amd import ops
 
         names = ("batch_norm_act_supported", "dense_conv", "depthwise_conv2d", "stem_pool_supported", "add_layer_norm_supported",
-                 "linear", "self_attention_supported", "embedding", "conv_transpose2x2", "concat_buffer_supported")
+                 "linear", "self_attention_supported", "embedding", "conv_transpose2x2", "concat_buffer_supported",
+                 "dense_conv_pair")
         self.ops, self.saved = ops, {n: getattr(ops, n) for n in names}
         ops.batch_norm_act_supported = lambda x, c: False
         ops.concat_buffer_supported = lambda x, parts: False  # torch.cat
+        ops.dense_conv_pair = lambda x, wa, wb, pa, pb, sa=None, sb=None: (F.conv2d(x, wa, None, 1, pa), F.conv2d(x, wb, None, 1, pb))
         ops.dense_conv = lambda x, w, stride=1, padding=0, pad_br=None, stats=None, out=None: F.conv2d(
             F.pad(x, (0, pad_br, 0, pad_br)) if pad_br else x, w, None, stride, padding)
         ops.depthwise_conv2d = lambda x, w, stride=1: F.conv2d(x, w, None, stride, (w.shape[-1] - 1) // 2, 1, x.shape[1])
