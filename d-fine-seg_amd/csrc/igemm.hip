@@ -389,7 +389,7 @@ static int ig_dispatch_k(const void* A, const void* Bw, void* C, const float* bi
     return e ? atoi(e) : 0;
   }();
   const int pad64 = (g.K + 63) / 64 * 64, pad32 = (g.K + 31) / 32 * 32;
-  bool use64 = pad64 == pad32 || g.K >= 1024;
+  bool use64 = (pad64 == pad32 && g.K > 64) || g.K >= 1024;  // K <= 64 (the stem's 2x2 convs): one or two short steps, occupancy wins
   if (forced == 32) use64 = false;
   if (forced == 64) use64 = true;
   if (use64) return ig_dispatch_n<64, VEC, OVEC, GATHER>(A, Bw, C, bias, stats, g, stream);
