@@ -19,7 +19,7 @@ SIGNATURES = {
     "dfine_msda_fwd": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]
     + [_c_int] * 6
     + [_i32p, _i32p, _c_void_p],
-    "dfine_msda_bwd": [_c_void_p, _c_int] + [_c_void_p] * 6 + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
+    "dfine_msda_bwd": [_c_void_p, _c_int] + [_c_void_p] * 4 + [_c_int] + [_c_void_p] * 2 + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
     "dfine_match_cost": [_c_void_p] * 6 + [_c_int] * 5 + [ctypes.c_float] * 5 + [_c_void_p],
     "dfine_lsap": [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p],
     "dfine_go_union": [_c_void_p] * 2 + [_c_int] * 3 + [_c_void_p],
@@ -47,6 +47,7 @@ SIGNATURES = {
     "dfine_msda_bwd_points": [_c_void_p, _c_int] + [_c_void_p] * 5 + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
     "dfine_msda_bwd_value": [_c_int] + [ctypes.POINTER(_c_void_p)] * 3 + [_c_int, _c_void_p] + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
     "dfine_mask_targets_nearest": [_c_void_p, _c_void_p, ctypes.c_longlong] + [_c_int] * 6 + [_c_void_p],
+    "dfine_row_max": [_c_void_p, _c_int, _c_void_p, ctypes.c_longlong, _c_int, _c_void_p],
     "dfine_stage_images": [_c_void_p, _c_void_p] + [_c_int] * 6 + [_c_void_p] * 3,
     "dfine_postprocess_topk": [_c_void_p, _c_int] + [_c_void_p] * 6 + [_c_int] * 7 + [_c_void_p],
     "dfine_postprocess_masks": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_int] * 8 + [ctypes.c_float, _c_void_p],
@@ -61,7 +62,7 @@ SIGNATURES = {
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int, _c_void_p, _c_int, _c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 11
 _lib = None
 
 IGEMM_MAX_TAPS = 16

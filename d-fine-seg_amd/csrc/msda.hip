@@ -116,11 +116,17 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const T* __restrict__ val
 // for global_atomic_add_f32 on gfx950). grad_attn / grad_loc need a sum over the pair's
 // channels: a shuffle tree over C lanes, written by the pair's first lane.
 // ------------------------------------------------------------------------------------------
-template <typename T, int C, bool SCATTER>
+// PK: grad_value is a bf16 map and the scatter uses global_atomic_pk_add_bf16 -- even lanes add (own, right neighbour's)
+// channel pair, 64 bytes per corner instead of 128. The float-atomic rate is the floor of this kernel (788 MB per layer
+// at ~1.3 TB/s); measured with the same access pattern (tools/micro/atomic_rate.hip) the packed form moves the same
+// bytes per second, i.e. twice the adds: 585 -> 296 us per layer's worth. Accumulating in bf16 is what stock autocast does
+// for this op (grid_sample's backward adds into a bf16 tensor with packed atomics as well).
+template <typename T, int C, bool SCATTER, bool PK = false>
 __global__ __launch_bounds__(256) void msda_bwd_kernel(
     const T* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
-    const T* __restrict__ grad_out, float* __restrict__ grad_value, float* __restrict__ grad_loc,
+    const T* __restrict__ grad_out, void* __restrict__ grad_value_, float* __restrict__ grad_loc,
     float* __restrict__ grad_attn, MsdaGeom g, int n_pairs, int S, int Lq, int nH) {
+  float* const grad_value = static_cast<float*>(grad_value_);
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int pair = tid / C;
   // n_pairs*C is padded to the block size by the host, so whole C-lane groups are either
@@ -167,7 +173,21 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
       }
       // d out / d value: scatter-add, fp32, no return value.
       const float ga_go = go * a;
-      if (SCATTER && live) {
+      if (SCATTER && PK) {
+        typedef short short2v __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(1))) short2v gptr;
+        bf16_t* const gv16 = static_cast<bf16_t*>(grad_value_) + head_off;
+        const float c00 = ga_go * k.w00, c01 = ga_go * k.w01, c10 = ga_go * k.w10, c11 = ga_go * k.w11;
+        // the right neighbour's contributions (every lane of the wave takes part in the shuffles)
+        const float n00 = __shfl_xor(c00, 1, 64), n01 = __shfl_xor(c01, 1, 64), n10 = __shfl_xor(c10, 1, 64), n11 = __shfl_xor(c11, 1, 64);
+        if (live && (ch & 1) == 0) {
+          short2v v;
+          if (b00) { v[0] = (short)f32_to_bf16(c00), v[1] = (short)f32_to_bf16(n00); __builtin_amdgcn_global_atomic_fadd_v2bf16((gptr*)(gv16 + o00), v); }
+          if (b01) { v[0] = (short)f32_to_bf16(c01), v[1] = (short)f32_to_bf16(n01); __builtin_amdgcn_global_atomic_fadd_v2bf16((gptr*)(gv16 + o01), v); }
+          if (b10) { v[0] = (short)f32_to_bf16(c10), v[1] = (short)f32_to_bf16(n10); __builtin_amdgcn_global_atomic_fadd_v2bf16((gptr*)(gv16 + o10), v); }
+          if (b11) { v[0] = (short)f32_to_bf16(c11), v[1] = (short)f32_to_bf16(n11); __builtin_amdgcn_global_atomic_fadd_v2bf16((gptr*)(gv16 + o11), v); }
+        }
+      } else if (SCATTER && live) {
         if (b00) atomicAdd(gvbase + o00, ga_go * k.w00);
         if (b01) atomicAdd(gvbase + o01, ga_go * k.w01);
         if (b10) atomicAdd(gvbase + o10, ga_go * k.w10);
@@ -375,16 +395,16 @@ static int launch_bwd_value(const MsdaCalls& calls, float* grad_value, const Msd
   return 0;
 }
 
-template <typename T, int C, bool SCATTER = true>
+template <typename T, int C, bool SCATTER = true, bool PK = false>
 static int launch_bwd(const void* value, const float* loc, const float* attn,
-                      const void* grad_out, float* grad_value, float* grad_loc, float* grad_attn,
+                      const void* grad_out, void* grad_value, float* grad_loc, float* grad_attn,
                       const MsdaGeom& g, int B, int S, int Lq, int nH, hipStream_t st) {
   const long long n_pairs = (long long)B * Lq * nH;
   const long long threads = n_pairs * C;
   const int block = 256;
   const long long grid = (threads + block - 1) / block;
   if (grid > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
-  hipLaunchKernelGGL((msda_bwd_kernel<T, C, SCATTER>), dim3((unsigned)grid), dim3(block), 0, st,
+  hipLaunchKernelGGL((msda_bwd_kernel<T, C, SCATTER, PK>), dim3((unsigned)grid), dim3(block), 0, st,
                      (const T*)value, loc, attn, (const T*)grad_out, grad_value, grad_loc,
                      grad_attn, g, (int)n_pairs, S, Lq, nH);
   DFINE_LAUNCH_CHECK();
@@ -418,7 +438,7 @@ extern "C" int dfine_msda_fwd(const void* value, int value_dtype, const float* l
 }
 
 extern "C" int dfine_msda_bwd(const void* value, int value_dtype, const float* loc,
-                              const float* attn, const void* grad_out, float* grad_value,
+                              const float* attn, const void* grad_out, void* grad_value, int grad_value_dtype,
                               float* grad_loc, float* grad_attn, int B, int S, int Lq, int nH,
                               int c, int n_levels, const int32_t* level_hw,
                               const int32_t* num_points, void* stream) {
@@ -429,6 +449,13 @@ extern "C" int dfine_msda_bwd(const void* value, int value_dtype, const float* l
   MsdaGeom g;
   if (int rc = make_geom(&g, S, n_levels, level_hw, num_points)) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (grad_value_dtype == DFINE_DT_BF16) {  // packed bf16 atomics into a bf16 gradient map
+    if (value_dtype != DFINE_DT_BF16 || (uintptr_t)grad_value % 4 != 0) return DFINE_E_UNSUPPORTED;
+    if (c == 32) return launch_bwd<bf16_t, 32, true, true>(value, loc, attn, grad_out, grad_value, grad_loc, grad_attn, g, B, S, Lq, nH, st);
+    if (c == 16) return launch_bwd<bf16_t, 16, true, true>(value, loc, attn, grad_out, grad_value, grad_loc, grad_attn, g, B, S, Lq, nH, st);
+    return DFINE_E_UNSUPPORTED;
+  }
+  if (grad_value_dtype != DFINE_DT_F32) return DFINE_E_UNSUPPORTED;
   if (value_dtype == DFINE_DT_BF16 && c == 32)
     return launch_bwd<bf16_t, 32>(value, loc, attn, grad_out, grad_value, grad_loc, grad_attn, g,
                                   B, S, Lq, nH, st);

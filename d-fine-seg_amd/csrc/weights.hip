@@ -116,9 +116,39 @@ __global__ __launch_bounds__(256) void stage_images_kernel(const unsigned char* 
   }
 }
 
+// Row maximum of a [M, C] matrix (query selection: the best class logit of each of the 8 400 encoder tokens, reference
+// dfine_decoder.py:905 enc_outputs_logits.max(-1).values feeding topk): 16 lanes per row, shuffle reduction. ATen's generic
+// inner-dimension reduction takes 166 us for the 43 MB of D-FINE-m at batch 32.
+template <typename T>
+__global__ __launch_bounds__(256) void row_max_kernel(const T* __restrict__ x, float* __restrict__ out, long long M, int C) {
+  const int sub = threadIdx.x & 15;
+  const long long row = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  float m = -INFINITY;
+  if (row < M)
+    for (int c = sub; c < C; c += 16) m = fmaxf(m, VecTraits<T>::load1(x + row * C + c));
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (row < M && sub == 0) out[row] = m;
+}
+
 }  // namespace dfine
 
 using namespace dfine;
+
+extern "C" int dfine_row_max(const void* x, int dtype, float* out, long long M, int C, void* stream) {
+  if (!x || !out) return DFINE_E_BADARG;
+  if (M <= 0 || C <= 0) return DFINE_E_BADARG;
+  const long long blocks = (M * 16 + 255) / 256;
+  if (blocks > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
+  if (dtype == DFINE_DT_F32)
+    hipLaunchKernelGGL(row_max_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, out, M, C);
+  else if (dtype == DFINE_DT_BF16)
+    hipLaunchKernelGGL(row_max_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, M, C);
+  else
+    return DFINE_E_UNSUPPORTED;
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int dfine_mask_targets_nearest(const unsigned char* masks, float* out, long long n_maps, int H, int W, int Hv, int Wv,
                                           int Hm, int Wm, void* stream) {

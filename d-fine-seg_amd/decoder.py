@@ -347,7 +347,7 @@ class DFINETransformer(nn.Module):
             # the differentiable branch is re-run on the Q selected rows, the only ones with a gradient
             if topk_ind is None:
                 with torch.no_grad():
-                    scores = self.enc_score_head(self.enc_output(memory * valid.to(memory.dtype))).max(-1).values
+                    scores = ops.row_max(self.enc_score_head(self.enc_output(memory * valid.to(memory.dtype))))
                     topk_ind = torch.topk(scores, Q, dim=-1).indices
             topk_mem = self.enc_output(ops.select_rows(memory, topk_ind, valid, sink))
             topk_logits = self.enc_score_head(topk_mem)

@@ -113,13 +113,17 @@ class _MSDeformAttnCore(torch.autograd.Function):
             if sink is not None and sink.buffer is not None:
                 grad_value = sink.buffer
             else:
-                grad_value = torch.zeros(B, S, nH, c, dtype=torch.float32, device=value.device)
+                # bf16 values (the training path): a bf16 map and PACKED bf16 atomics -- half the atomic bytes, the floor of
+                # this kernel; the precision of stock autocast's grid_sample backward (DFINE_MSDA_GRAD=f32: float atomics)
+                gdt = torch.bfloat16 if (value.dtype == torch.bfloat16 and MSDA_GRAD_BF16) else torch.float32
+                grad_value = torch.zeros(B, S, nH, c, dtype=gdt, device=value.device)
                 if sink is not None:
                     sink.buffer = grad_value
             with _lib.timed("msda_bwd", msda_algorithmic_bytes(B, Lq, nH, loc.shape[3], c, value.element_size())[1]):
                 rc = lib.dfine_msda_bwd(
                     _lib.ptr(value), _lib.dtype_code(value), _lib.ptr(loc), _lib.ptr(attn), _lib.ptr(grad_out), _lib.ptr(grad_value),
-                    _lib.ptr(grad_loc), _lib.ptr(grad_attn), B, S, Lq, nH, c, len(num_points), hw, npts, _lib.stream_ptr())
+                    _lib.dtype_code(grad_value), _lib.ptr(grad_loc), _lib.ptr(grad_attn), B, S, Lq, nH, c, len(num_points), hw, npts,
+                    _lib.stream_ptr())
             _lib.check(rc, "dfine_msda_bwd")
             if sink is not None and not ctx.finalize:
                 sink.expect_consumer()
@@ -148,6 +152,7 @@ class _MSDeformAttnCore(torch.autograd.Function):
 import os as _os
 
 MSDA_VALUE_GRAD = "slab" if _os.environ.get("DFINE_MSDA_VALUE", "") == "slab" else "atomic"
+MSDA_GRAD_BF16 = _os.environ.get("DFINE_MSDA_GRAD", "bf16") != "f32"  # "atomic" mode with bf16 values: packed bf16 atomics
 
 
 class ValueGradSink:
@@ -199,7 +204,7 @@ class ValueGradSink:
                     scratch_l, scratch_a = torch.empty_like(loc), torch.empty_like(attn)
                     dummy_value = torch.zeros(B, S, nH, c, dtype=dtype, device=device)
                     rc2 = lib.dfine_msda_bwd(_lib.ptr(dummy_value), code, _lib.ptr(loc), _lib.ptr(attn), _lib.ptr(go), _lib.ptr(part),
-                                             _lib.ptr(scratch_l), _lib.ptr(scratch_a), B, S, Lq, nH, c, len(num_points), hw, npts,
+                                             _lib.DT_F32, _lib.ptr(scratch_l), _lib.ptr(scratch_a), B, S, Lq, nH, c, len(num_points), hw, npts,
                                              _lib.stream_ptr())
                     _lib.check(rc2, "dfine_msda_bwd")
             else:
@@ -249,7 +254,7 @@ class _SelectRows(torch.autograd.Function):
         total = sink.flush() if sink is not None else None  # every deformable-attention call's value gradient, one launch
         if total is None:
             total = torch.zeros(B, S, D, dtype=torch.float32, device=g.device)
-        total.view(B, S, D).scatter_add_(1, idx_e, (g * scale).float())
+        total.view(B, S, D).scatter_add_(1, idx_e, (g * scale).to(total.dtype))
         return total.view(B, S, D).to(ctx.dtype), None, None, None
 
 
@@ -796,6 +801,19 @@ def upsample_nearest2x(x, into=None):
 
 def upsample_nearest2x_supported(x):
     return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0
+
+
+def row_max(x):
+    """``x.max(-1).values`` as float32 for a dense bf16 / fp32 CUDA tensor, one HIP launch (query selection's best class
+    logit per token); not differentiable. Anything else goes to ATen."""
+    if not (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous()) or (torch.is_grad_enabled() and x.requires_grad):
+        return x.max(-1).values
+    lib = _lib.load()
+    C = x.shape[-1]
+    out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    rc = lib.dfine_row_max(_lib.ptr(x), _lib.dtype_code(x), _lib.ptr(out), x.numel() // C, C, _lib.stream_ptr())
+    _lib.check(rc, "dfine_row_max")
+    return out
 
 
 def stem_pool_supported(x):

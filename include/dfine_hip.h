@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 9
+#define DFINE_ABI_VERSION 11
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -61,6 +61,9 @@ int dfine_abi_version(void);
  *   level_hw   host int32 [n_levels][2] (H_l, W_l)
  *   num_points host int32 [n_levels]
  * Supported: c in {16, 32}; n_levels <= DFINE_MAX_LEVELS; P <= DFINE_MAX_POINTS.
+  *   grad_value_dtype: DFINE_DT_F32 (float atomics into an f32 map) or, for bf16 values, DFINE_DT_BF16: the gradient map is
+ *   bf16 and the scatter uses packed bf16 atomics (two channels per add) -- half the atomic bytes, which are the floor of
+ *   this kernel, and the accumulation precision of the stock bf16 autocast path (grid_sample's backward).
  * ------------------------------------------------------------------------------------- */
 int dfine_msda_fwd(const void* value, int value_dtype, const float* loc, const float* attn,
                    void* out, int B, int S, int Lq, int nH, int c, int n_levels,
@@ -76,7 +79,7 @@ int dfine_msda_fwd(const void* value, int value_dtype, const float* loc, const f
  *   grad_attn  [B, Lq, nH, P]    f32    overwritten
  */
 int dfine_msda_bwd(const void* value, int value_dtype, const float* loc, const float* attn,
-                   const void* grad_out, float* grad_value, float* grad_loc, float* grad_attn,
+                   const void* grad_out, void* grad_value, int grad_value_dtype, float* grad_loc, float* grad_attn,
                    int B, int S, int Lq, int nH, int c, int n_levels, const int32_t* level_hw,
                    const int32_t* num_points, void* stream);
 
@@ -492,6 +495,13 @@ int dfine_mask_targets_nearest(const unsigned char* masks, float* out, long long
  * ------------------------------------------------------------------------------------- */
 int dfine_stage_images(const unsigned char* src, void* dst, int dtype, int B, int H, int W, int OH, int OW,
                        const float* mean, const float* std, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Row maximum, out[m] = max_c x[m][c] (query selection: reference src/d_fine/arch/dfine_decoder.py:905
+ * enc_outputs_logits.max(-1).values, whose top-k picks the decoder queries): x [M, C] bf16 or f32 dense, out f32 [M].
+ * Not differentiable (the reference takes indices from it only).
+ * ------------------------------------------------------------------------------------- */
+int dfine_row_max(const void* x, int dtype, float* out, long long M, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Deformable-attention backward split so that the value gradient needs no global atomics:

@@ -160,7 +160,7 @@ def test_value_gradient_without_global_atomics_matches_the_atomic_kernel(hip_lib
     ref_pts = []
     for loc, attn, go in calls:
         gl, ga = torch.empty_like(loc), torch.empty_like(attn)
-        assert hip_lib.dfine_msda_bwd(_lib.ptr(value), 1, _lib.ptr(loc), _lib.ptr(attn), _lib.ptr(go), _lib.ptr(ref_value), _lib.ptr(gl),
+        assert hip_lib.dfine_msda_bwd(_lib.ptr(value), 1, _lib.ptr(loc), _lib.ptr(attn), _lib.ptr(go), _lib.ptr(ref_value), 0, _lib.ptr(gl),
                                       _lib.ptr(ga), B, S, Lq, nH, c, len(npts), hw, np_, None) == 0
         ref_pts.append((gl, ga))
     outs = []
@@ -179,3 +179,41 @@ def test_value_gradient_without_global_atomics_matches_the_atomic_kernel(hip_lib
     torch.testing.assert_close(outs[0], ref_value, rtol=1e-4, atol=1e-4)
     # (LDS float atomics still reorder adds inside a slab, so the two runs agree to round-off, not bit for bit)
     torch.testing.assert_close(outs[0], outs[1], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,shapes,npts", [(32, [(80, 80), (40, 40), (20, 20)], [3, 6, 3]), (16, [(20, 20), (10, 10)], [6, 6])])
+def test_packed_bf16_value_gradient_matches_the_float_one(hip_lib, c, shapes, npts):
+    """dfine_msda_bwd with a bf16 gradient map (global_atomic_pk_add_bf16, two channels per add) against the float-atomic
+    form on the same inputs, four calls accumulating into one map like the four decoder layers: grad_loc / grad_attn bit-equal;
+    the value gradient within bf16 ACCUMULATION round-off -- every add rounds the running sum to 8 mantissa bits, so with n
+    adds per element the error random-walks to ~sqrt(n) * 2^-9 of the sum: relative L2 < 1.5e-2 over the map, and no element
+    off by more than 6 % of the map's largest magnitude."""
+    from dfine_seg_amd import _lib
+
+    B, Lq, nH = 4, 300, 8
+    S, P = sum(h * w for h, w in shapes), sum(npts)
+    g = torch.Generator(device="cuda").manual_seed(7 + c)
+    value = torch.randn(B, S, nH, c, device="cuda", generator=g).bfloat16()
+    hw = _lib.i32_array(v for pair in shapes for v in pair)
+    np_ = _lib.i32_array(npts)
+    g32 = torch.zeros(B, S, nH, c, device="cuda")
+    g16 = torch.zeros(B, S, nH, c, device="cuda", dtype=torch.bfloat16)
+    for _ in range(4):
+        loc = (torch.rand(B, Lq, nH, P, 2, device="cuda", generator=g) * 1.2 - 0.1).contiguous()
+        attn = torch.softmax(torch.randn(B, Lq, nH, P, device="cuda", generator=g), -1).contiguous()
+        go = torch.randn(B, Lq, nH * c, device="cuda", generator=g).bfloat16()
+        gl0, ga0, gl1, ga1 = torch.empty_like(loc), torch.empty_like(attn), torch.empty_like(loc), torch.empty_like(attn)
+        assert hip_lib.dfine_msda_bwd(_lib.ptr(value), 1, _lib.ptr(loc), _lib.ptr(attn), _lib.ptr(go), _lib.ptr(g32), 0, _lib.ptr(gl0),
+                                      _lib.ptr(ga0), B, S, Lq, nH, c, len(npts), hw, np_, None) == 0
+        assert hip_lib.dfine_msda_bwd(_lib.ptr(value), 1, _lib.ptr(loc), _lib.ptr(attn), _lib.ptr(go), _lib.ptr(g16), 1, _lib.ptr(gl1),
+                                      _lib.ptr(ga1), B, S, Lq, nH, c, len(npts), hw, np_, None) == 0
+        assert torch.equal(gl0, gl1) and torch.equal(ga0, ga1)
+    torch.cuda.synchronize()
+    diff = (g16.float() - g32)
+    assert float(diff.norm() / g32.norm()) < 1.5e-2, float(diff.norm() / g32.norm())
+    assert float(diff.abs().max()) < 0.06 * float(g32.abs().max())
+    # fp32 values with a bf16 map are refused (the packed form is for the bf16 training path)
+    v32 = value.float()
+    assert hip_lib.dfine_msda_bwd(_lib.ptr(v32), 0, _lib.ptr(loc), _lib.ptr(attn), _lib.ptr(go.float()), _lib.ptr(g16), 1, _lib.ptr(gl1),
+                                  _lib.ptr(ga1), B, S, Lq, nH, c, len(npts), hw, np_, None) == -2

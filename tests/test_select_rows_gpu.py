@@ -60,3 +60,16 @@ def test_unfinalized_sink_fails_loudly(hip_lib):
     with pytest.raises(RuntimeError, match="never handed to autograd"):
         out.sum().backward()
     assert not sink.pending and sink.buffer is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dtype", [((3, 8400, 80), torch.bfloat16), ((2, 525, 80), torch.float32), ((5, 37, 7), torch.bfloat16), ((1, 1, 300), torch.float32)])
+def test_row_max_equals_torch(hip_lib, shape, dtype):
+    """dfine_row_max (the best class logit per encoder token, whose top-k selects the decoder queries): exact."""
+    from dfine_seg_amd import ops
+
+    x = torch.randn(*shape, device="cuda").to(dtype)
+    x[0, 0, -1] = 50.0
+    with torch.no_grad():
+        got = ops.row_max(x)
+    assert got.dtype == torch.float32 and torch.equal(got, x.float().max(-1).values)
