@@ -159,9 +159,9 @@ class HybridEncoder(nn.Module):
         # PAN's downsampled map are WRITTEN into their halves of the block's input buffer by the kernels that produce them
         # (the stock cat of a channels_last and an NCHW-dense operand also cost a layout-conversion copy each way)
         buffered = self.training and ops.concat_buffer_supported(feats[-1], [self.hidden, self.hidden])
-        proj = [None] * len(feats)
-        proj[-1] = self.input_proj[-1](feats[-1])
-        if not buffered:
+        if buffered:  # the finer levels' projections are computed later, straight into the FPN buffers
+            proj = [None] * (len(feats) - 1) + [self.input_proj[-1](feats[-1])]
+        else:
             proj = [p(f) for p, f in zip(self.input_proj, feats)]
         x = proj[-1]
         B, C, h, w = x.shape
