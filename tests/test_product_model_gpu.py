@@ -5,6 +5,8 @@ meaningful (SURVEY.md 7 "Hard parts").
 
 fp32 run: tolerance = kernel/op-order noise of an fp32 GPU pipeline vs fp32 CPU.
 bf16 run (autocast, as trained): per-tensor relative L2 <= the bounds written below."""
+import os
+
 import pytest
 import torch
 
@@ -141,15 +143,9 @@ class _StockOps:
         return False
 
 
-def test_bf16_stage_errors_are_bounded_and_below_stock_autocast(hip_lib):
-    """Stage-wise bf16 accuracy of the path that is trained and benchmarked (D-FINE-m, name-hashed weights, the 2-image golden
-    batch; train-mode BatchNorm): each stage is fed the SAME fp32-computed input and its bf16 output is compared with its
-    fp32 output (whose end-to-end agreement with the reference is pinned at 2e-4 above), next to the same modules run as stock
-    PyTorch bf16 autocast. With random weights and a 2-image batch, round-off grows ~7 % per BatchNorm layer in ANY bf16
-    pipeline (profiles/r02_bf16_error_by_layer.txt: stock autocast reaches 1.08 at the end of the backbone and 1.2-1.36 in
-    the encoder; the reference's own 0.27-0.41 in model_m640.npz is its CPU autocast, which keeps BatchNorm outputs in fp32).
-    The product rounds once per layer (conv -> fused norm+act+LAB in fp32 -> bf16) instead of after every op and must stay
-    BELOW the stock pipeline at every stage, and within the absolute bounds written here (measured x 1.5)."""
+def _stage_errors(stock):
+    """Relative L2 distance to fp32 of the three backbone maps and of the three encoder maps (the encoder alone, fed the fp32
+    features), for the product's bf16 path or for the same modules as stock PyTorch bf16 autocast: ([3], [3])."""
     g, model, crit, x, targets, inject, seg = _setup("model_m640")
     model.train()
     state = {k: v.clone() for k, v in model.state_dict().items()}
@@ -158,8 +154,7 @@ def test_bf16_stage_errors_are_bounded_and_below_stock_autocast(hip_lib):
     def stages(autocast):
         model.load_state_dict(state)  # identical BatchNorm running statistics for every run
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
-            feats = model.backbone(xcl)
-        return feats
+            return model.backbone(xcl)
 
     def encoder_from(feats, autocast):
         model.load_state_dict(state)
@@ -169,29 +164,62 @@ def test_bf16_stage_errors_are_bounded_and_below_stock_autocast(hip_lib):
 
     feats32 = stages(False)
     outs32 = encoder_from(feats32, False)
-    feats16 = stages(True)
-    outs16 = encoder_from(feats32, True)  # encoder alone: fed the fp32 features
-    with _StockOps():
-        feats_st = stages(True)
-        outs_st = encoder_from(feats32, True)
+    if stock:
+        with _StockOps():
+            feats16, outs16 = stages(True), encoder_from(feats32, True)
+    else:
+        feats16, outs16 = stages(True), encoder_from(feats32, True)
+    torch.cuda.synchronize()
+    return ([_rel(feats16[l].float().cpu(), feats32[l].float().cpu()) for l in range(3)],
+            [_rel(outs16[l].float().cpu(), outs32[l].float().cpu()) for l in range(3)])
+
+
+def _stock_stage_errors_worker(path):
+    torch.save(_stage_errors(True), path)
+
+
+def _in_child(worker, path, timeout=900):
+    """Run ``worker(path)`` in a spawned process (the stock MIOpen pipeline can take the process down, see below); the loaded
+    result, or None if the child died."""
+    import multiprocessing as mp
+
+    child = mp.get_context("spawn").Process(target=worker, args=(path,))
+    child.start()
+    child.join(timeout)
+    if child.is_alive():
+        child.kill()
+        child.join()
+    return torch.load(path, weights_only=True) if child.exitcode == 0 and os.path.exists(path) else None
+
+
+def test_bf16_stage_errors_are_bounded_and_below_stock_autocast(hip_lib, tmp_path):
+    """Stage-wise bf16 accuracy of the path that is trained and benchmarked (D-FINE-m, name-hashed weights, the 2-image golden
+    batch; train-mode BatchNorm): each stage is fed the SAME fp32-computed input and its bf16 output is compared with its
+    fp32 output (whose end-to-end agreement with the reference is pinned at 2e-4 above), next to the same modules run as stock
+    PyTorch bf16 autocast. With random weights and a 2-image batch, round-off grows ~7 % per BatchNorm layer in ANY bf16
+    pipeline (profiles/r02_bf16_error_by_layer.txt: stock autocast reaches 1.08 at the end of the backbone and 1.2-1.36 in
+    the encoder; the reference's own 0.27-0.41 in model_m640.npz is its CPU autocast, which keeps BatchNorm outputs in fp32).
+    The product rounds once per layer (conv -> fused norm+act+LAB in fp32 -> bf16) instead of after every op and must stay
+    BELOW the stock pipeline at every stage, and within the absolute bounds written here (measured x 1.5). The stock pipeline
+    runs in a child process (see test_bf16_train_step_gradients_vs_fp32_and_stock_autocast); without it only the absolute
+    bounds are enforced."""
+    prod_b, prod_e = _stage_errors(False)
+    stock = _in_child(_stock_stage_errors_worker, str(tmp_path / "stock_stage_errors.pt"))
     bounds_backbone, bounds_encoder = (0.12, 0.30, 0.45), (0.75, 0.90, 1.05)
     for lvl in range(3):
-        e_prod, e_stock = _rel(feats16[lvl].float().cpu(), feats32[lvl].float().cpu()), _rel(feats_st[lvl].float().cpu(), feats32[lvl].float().cpu())
-        assert e_prod < 0.6 * e_stock and e_prod < bounds_backbone[lvl], ("backbone", lvl, e_prod, e_stock)
-        e_prod, e_stock = _rel(outs16[lvl].float().cpu(), outs32[lvl].float().cpu()), _rel(outs_st[lvl].float().cpu(), outs32[lvl].float().cpu())
-        assert e_prod < e_stock and e_prod < bounds_encoder[lvl], ("encoder", lvl, e_prod, e_stock)
+        assert prod_b[lvl] < bounds_backbone[lvl], ("backbone", lvl, prod_b[lvl])
+        assert prod_e[lvl] < bounds_encoder[lvl], ("encoder", lvl, prod_e[lvl])
+        if stock is not None:
+            assert prod_b[lvl] < 0.6 * stock[0][lvl], ("backbone", lvl, prod_b[lvl], stock[0][lvl])
+            assert prod_e[lvl] < stock[1][lvl], ("encoder", lvl, prod_e[lvl], stock[1][lvl])
+    if stock is None:
+        pytest.skip("the stock bf16 pipeline (MIOpen) crashed in its child process: only the absolute bounds were checked")
 
 
-def test_bf16_train_step_gradients_vs_fp32_and_stock_autocast(hip_lib):
-    """The gradients the benchmarked path feeds its optimizer -- bf16 shadow weights, implicit-GEMM / attention kernels, the
-    wgrad kernels accumulating straight into the flat fp32 gradient buffer (TrainStep, amp=True) -- against (a) the fp32
-    gradients of the same step (pinned to the reference by grad norms above) and (b) the gradients stock PyTorch bf16 autocast
-    + autograd produces for the same modules. D-FINE-s (not n: MIOpen's stock BatchNorm segfaults on n's 21-channel bf16 maps,
-    DESIGN.md 4), reference noise / query selection injected. Bound: cosine similarity
-    with the fp32 gradient >= the stock pipeline's minus 0.03 and >= 0.5, for the whole model and for each of backbone /
-    encoder / decoder. (Measured, whole model: product 0.65, stock autocast 0.59 -- with random weights and BatchNorm over 2
-    images NO bf16 pipeline tracks the fp32 gradient closely, see profiles/r02_bf16_error_by_layer.txt; the product must not be
-    the worse of the two.)"""
+def _step_gradients(amp, stock):
+    """Gradients of one D-FINE-s training step (name-hashed weights, golden batch, injected noise / query selection) through
+    TrainStep's forward + backward: fp32 (amp=False), the product's bf16 path, or the same modules as stock PyTorch bf16."""
+    from dfine_seg_amd.targets import TargetBatch
     from dfine_seg_amd.train import TrainStep
 
     size, img, n_gts, seg = MODEL_CASES["model_s640"]
@@ -201,24 +229,39 @@ def test_bf16_train_step_gradients_vs_fp32_and_stock_autocast(hip_lib):
     torch.manual_seed(SEED_CDN)
     noise = oracle_ops.cdn_noise(n_gts, 80)
     inject = {"topk_ind": torch.as_tensor(gold["topk_ind"]).cuda(), "cdn_noise": {k: v.cuda() for k, v in noise.items()}}
-
-    def grads(amp, stock):
-        t = TrainStep(size, 80, False, (img, img), "cuda", amp=amp, use_graph=False)
-        sd = weights.fill_state_dict(t.model.state_dict())
-        t.model.load_state_dict(sd, strict=True)
-        t.flat.refresh_bf16_shadow()
-        from dfine_seg_amd.targets import TargetBatch
-
-        tb = TargetBatch.from_list(targets, 80, t.device)
-        if stock:
-            with _StockOps():
-                t._forward_backward(x, tb, inject)
-        else:
+    t = TrainStep(size, 80, False, (img, img), "cuda", amp=amp, use_graph=False)
+    sd = weights.fill_state_dict(t.model.state_dict())
+    t.model.load_state_dict(sd, strict=True)
+    t.flat.refresh_bf16_shadow()
+    tb = TargetBatch.from_list(targets, 80, t.device)
+    if stock:
+        with _StockOps():
             t._forward_backward(x, tb, inject)
-        torch.cuda.synchronize()
-        return {n: p.grad.detach().float().clone() for n, p in t.model.named_parameters() if p.requires_grad}
+    else:
+        t._forward_backward(x, tb, inject)
+    torch.cuda.synchronize()
+    return {n: p.grad.detach().float().cpu().clone() for n, p in t.model.named_parameters() if p.requires_grad}
 
-    g32, g_prod, g_stock = grads(False, False), grads(True, False), grads(True, True)
+
+def _stock_gradients_worker(path):
+    torch.save(_step_gradients(True, True), path)
+
+
+def test_bf16_train_step_gradients_vs_fp32_and_stock_autocast(hip_lib, tmp_path):
+    """The gradients the benchmarked path feeds its optimizer -- bf16 shadow weights, implicit-GEMM / attention kernels, the
+    wgrad kernels accumulating straight into the flat fp32 gradient buffer (TrainStep, amp=True) -- against (a) the fp32
+    gradients of the same step (pinned to the reference by grad norms above) and (b) the gradients stock PyTorch bf16 autocast
+    + autograd produces for the same modules. D-FINE-s, reference noise / query selection injected. Bound: cosine similarity
+    with the fp32 gradient >= the stock pipeline's minus 0.03 and >= 0.5, for the whole model and for each of backbone /
+    encoder / decoder. (Measured, whole model: product 0.65, stock autocast 0.59 -- with random weights and BatchNorm over 2
+    images NO bf16 pipeline tracks the fp32 gradient closely, see profiles/r02_bf16_error_by_layer.txt; the product must not be
+    the worse of the two.)
+    The STOCK pipeline runs in a child process: MIOpen's bf16 BatchNorm / convolution kernels have faulted on this GPU
+    ("Memory access fault", autograd thread inside an ATen node) depending on what the allocator hands them -- on D-FINE-n's
+    21-channel maps always, on this model when the suite's earlier tests leave the heap in a certain state. If the child dies
+    the comparison (b) is skipped and only the absolute bound (a) is enforced."""
+    g32, g_prod = _step_gradients(False, False), _step_gradients(True, False)
+    g_stock = _in_child(_stock_gradients_worker, str(tmp_path / "stock_grads.pt"))
 
     def cos(a, b, prefix=""):
         names = [n for n in g32 if n.startswith(prefix)]
@@ -226,8 +269,13 @@ def test_bf16_train_step_gradients_vs_fp32_and_stock_autocast(hip_lib):
         return float(torch.dot(va, vb) / (va.norm() * vb.norm()))
 
     for prefix in ("", "backbone.", "encoder.", "decoder."):
-        c_prod, c_stock = cos(g_prod, g32, prefix), cos(g_stock, g32, prefix)
-        assert c_prod >= 0.5 and c_prod >= c_stock - 0.03, (prefix, c_prod, c_stock)
+        c_prod = cos(g_prod, g32, prefix)
+        assert c_prod >= 0.5, (prefix, c_prod)
+        if g_stock is not None:
+            c_stock = cos(g_stock, g32, prefix)
+            assert c_prod >= c_stock - 0.03, (prefix, c_prod, c_stock)
+    if g_stock is None:
+        pytest.skip("the stock bf16 pipeline (MIOpen) crashed in its child process: only the fp32 bound was checked")
 
 
 @pytest.mark.parametrize("fname", ["model_m640", "model_m640_seg"])
