@@ -32,6 +32,7 @@ for r in rows:
     elif "igemm_bwd" in n or "conv_bwd_data" in n: k = "MIOpen conv input-gradient (igemm asm / CK xdl)"
     elif "igemm_wrw" in n or "conv_bwd_weight" in n: k = "MIOpen conv weight-gradient (stem convs with 3 / 12 input channels)"
     elif n.startswith("Cijk"): k = "hipBLASLt GEMM (Linear forward / input gradient)"
+    elif "dfine::" in n: k = "other dfine:: kernels the name filter lets through (msda / norm / pool backward, optimizer: no MFMA)"
     elif "attn" in n or "bwd_kernel" in n: k = "aotriton attention"
     else: k = "other xdl"
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
