@@ -23,7 +23,7 @@ SIGNATURES = {
     "dfine_match_cost": [_c_void_p] * 6 + [_c_int] * 5 + [ctypes.c_float] * 5 + [_c_void_p],
     "dfine_lsap": [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p],
     "dfine_go_union": [_c_void_p] * 2 + [_c_int] * 3 + [_c_void_p],
-    "dfine_dwconv_fwd": [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p],
+    "dfine_dwconv_fwd": [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p, _c_void_p],
     "dfine_dwconv_bwd_data": [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p],
     "dfine_dwconv_bwd_weight": [_c_void_p] * 4 + [ctypes.c_longlong] + [_c_int] * 7 + [_c_void_p],
     "dfine_dwconv_bwd_weight_workspace": [_c_int] * 6,
@@ -62,7 +62,7 @@ SIGNATURES = {
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int, _c_void_p, _c_int, _c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 _lib = None
 
 IGEMM_MAX_TAPS = 16

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const T* __restric
 // algorithmic HBM bytes and 0.8 TB/s effective). blockDim = (channel groups, strips).
 template <typename T, int K, int STRIP, bool FLIP>
 __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
-                                                           DwGeom g, int n_strips, int strips_per_row) {
+                                                           double* __restrict__ stats, DwGeom g, int n_strips, int strips_per_row) {
   constexpr int VEC = VecTraits<T>::kElems;
   constexpr int PAD = (K - 1) / 2;
   constexpr int WIN = STRIP + K - 1;
@@ -126,10 +126,15 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
   stage_weights<K>(w_s, w, c_base, c_slice, threadIdx.y * blockDim.x + threadIdx.x, blockDim.x * blockDim.y);
   __syncthreads();
   const int strip = blockIdx.x * blockDim.y + threadIdx.y;
-  if (strip >= n_strips) return;
+  const bool live = strip < n_strips;
+  const int c_loc = threadIdx.x * VEC;
+  if (!live && stats == nullptr) return;
+  float s1[VEC], s2[VEC];  // per-channel sum / sum of squares of the ROUNDED outputs (the BatchNorm that follows reads them)
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s1[i] = s2[i] = 0.f;
+  if (live) {
   const int sx = strip % strips_per_row, row = strip / strips_per_row;  // row = (b, oy); stride 1: OH = H, OW = W
   const int oy = row % g.H, b = row / g.H, ox0 = sx * STRIP;
-  const int c_loc = threadIdx.x * VEC;
   float acc[STRIP][VEC];
 #pragma unroll
   for (int s_ = 0; s_ < STRIP; ++s_)
@@ -165,7 +170,35 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
 #pragma unroll
   for (int s_ = 0; s_ < STRIP; ++s_) {
     const int ox = ox0 + s_;
-    if (ox < g.W) *reinterpret_cast<Vec16*>(y + ((size_t)row * g.W + ox) * g.C + c_base + c_loc) = VecTraits<T>::pack(acc[s_]);
+    if (ox >= g.W) continue;
+    const Vec16 pk = VecTraits<T>::pack(acc[s_]);
+    *reinterpret_cast<Vec16*>(y + ((size_t)row * g.W + ox) * g.C + c_base + c_loc) = pk;
+    if (stats != nullptr) {
+      float r[VEC];
+      VecTraits<T>::unpack(pk, r);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) s1[i] += r[i], s2[i] += r[i] * r[i];
+    }
+  }
+  }  // live
+  if (stats != nullptr) {
+    // column sums over the block's strips through LDS (behind the staged weights), then one fp64 atomic per (quantity,
+    // channel) into the 8-replica layout dfine_bn_act_fwd reads: the depthwise conv's BatchNorm needs no statistics pass
+    float* part = w_s + K * K * c_slice;  // [2][blockDim.y][c_slice]
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      part[(0 * blockDim.y + threadIdx.y) * c_slice + c_loc + i] = s1[i];
+      part[(1 * blockDim.y + threadIdx.y) * c_slice + c_loc + i] = s2[i];
+    }
+    __syncthreads();
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    for (int e = tid; e < 2 * c_slice; e += blockDim.x * blockDim.y) {  // c_slice can be the whole block (256 channels)
+      const int q = e / c_slice, c = e % c_slice;
+      float a = 0.f;
+      for (int r = 0; r < (int)blockDim.y; ++r) a += part[(q * blockDim.y + r) * c_slice + c];
+      atomicAdd(stats + ((size_t)(blockIdx.x & 7) * 2 + q) * g.C + c_base + c, (double)a);
+    }
   }
 }
 
@@ -280,7 +313,7 @@ static int largest_divisor_leq(int n, int cap) {
 
 template <typename T, int K, int S>
 static int run_fwd_or_bwd_data(bool fwd, const void* in, const float* w, void* out, const DwGeom& g,
-                               hipStream_t st) {
+                               hipStream_t st, double* stats = nullptr) {
   constexpr int VEC = VecTraits<T>::kElems;
   if (g.C % VEC != 0) return DFINE_E_UNSUPPORTED;
   const int cgb = largest_divisor_leq(g.C / VEC, 32);
@@ -292,14 +325,15 @@ static int run_fwd_or_bwd_data(bool fwd, const void* in, const float* w, void* o
     const long long n_strips = (long long)g.B * g.H * spr;
     if (n_strips > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
     dim3 block(cgb, pb), grid((unsigned)((n_strips + pb - 1) / pb), g.C / (cgb * VEC));
-    const size_t lds = (size_t)K * K * cgb * VEC * sizeof(float);
+    const size_t lds = (size_t)K * K * cgb * VEC * sizeof(float) + (stats ? (size_t)2 * pb * cgb * VEC * sizeof(float) : 0);
     if (fwd)
-      hipLaunchKernelGGL((dwconv_strip_kernel<T, K, STRIP, false>), grid, block, lds, st, (const T*)in, w, (T*)out, g, (int)n_strips, spr);
+      hipLaunchKernelGGL((dwconv_strip_kernel<T, K, STRIP, false>), grid, block, lds, st, (const T*)in, w, (T*)out, stats, g, (int)n_strips, spr);
     else
-      hipLaunchKernelGGL((dwconv_strip_kernel<T, K, STRIP, true>), grid, block, lds, st, (const T*)in, w, (T*)out, g, (int)n_strips, spr);
+      hipLaunchKernelGGL((dwconv_strip_kernel<T, K, STRIP, true>), grid, block, lds, st, (const T*)in, w, (T*)out, nullptr, g, (int)n_strips, spr);
     DFINE_LAUNCH_CHECK();
     return 0;
   }
+  if (stats) return DFINE_E_UNSUPPORTED;  // the statistics epilogue exists in the stride-1 strip kernel only
   const long long n_pix = fwd ? (long long)g.B * g.OH * g.OW : (long long)g.B * g.H * g.W;
   dim3 block(cgb, pb), grid((unsigned)((n_pix + pb - 1) / pb), g.C / (cgb * VEC));
   const size_t lds = (size_t)K * K * cgb * VEC * sizeof(float);
@@ -381,12 +415,13 @@ static int make_dw_geom(DwGeom* g, int B, int H, int W, int C, int k, int stride
 using namespace dfine;
 
 extern "C" int dfine_dwconv_fwd(const void* x, const float* w, void* y, int dtype, int B, int H,
-                                int W, int C, int k, int stride, void* stream) {
+                                int W, int C, int k, int stride, double* stats, void* stream) {
   if (!x || !w || !y) return DFINE_E_BADARG;
   DwGeom g;
   if (int rc = make_dw_geom(&g, B, H, W, C, k, stride)) return rc;
+  if (stats && stride != 1) return DFINE_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-#define CALL(T, K, S) run_fwd_or_bwd_data<T, K, S>(true, x, w, y, g, st)
+#define CALL(T, K, S) run_fwd_or_bwd_data<T, K, S>(true, x, w, y, g, st, stats)
   DFINE_DW_DISPATCH(CALL);
 #undef CALL
 }

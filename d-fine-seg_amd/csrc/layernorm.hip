@@ -8,6 +8,8 @@
 // One wave per row (D = 64 * E elements, E in {2, 4, 8}: each lane owns E consecutive elements = one
 // 4/8/16-byte access for bf16), statistics by wave shuffles in fp32. Backward accumulates d gamma / d beta
 // per lane over the rows a wave walks, then one LDS reduction and float atomics per workgroup.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dfine {
@@ -135,7 +137,8 @@ static int launch_ln(bool fwd, const void* a, const void* b, const float* gamma,
   // grid-stride over rows. Backward: every workgroup ends with 2*D float atomics on the SAME 2*D addresses;
   // 2048 workgroups made that tail 60 us of serialised same-address adds, 256 keep it under 10 us
   long long blocks = (M + 3) / 4;
-  const long long cap = fwd ? 2048 : 256;
+  static const int bwd_cap = getenv("DFINE_LN_BWD_BLOCKS") ? atoi(getenv("DFINE_LN_BWD_BLOCKS")) : 256;
+  const long long cap = fwd ? 2048 : bwd_cap;
   if (blocks > cap) blocks = cap;
   if (fwd)
     hipLaunchKernelGGL((add_ln_fwd_kernel<T, E>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)a, (const T*)b, gamma, beta,

@@ -132,7 +132,10 @@ class ConvNorm(nn.Module):
         conv = self.conv
         ws, have_stats = None, False
         if conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1:
-            x = ops.depthwise_conv2d(x, conv.weight, conv.stride[0])  # HIP: MIOpen has no fast path here
+            if ops.depthwise_stats_supported(conv.stride[0]) and x.dtype == torch.bfloat16:
+                ws, have_stats = self._stats_workspace(x)  # the strip kernel's epilogue leaves the statistics, like a dense conv's
+            x = ops.depthwise_conv2d(x, conv.weight, conv.stride[0],  # HIP: MIOpen has no fast path here
+                                     stats=ws[: 32 * conv.out_channels] if have_stats else None)
         elif (conv.groups == 1 and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1]
               and isinstance(conv.padding[0], int) and conv.dilation == (1, 1)):
             # HIP implicit-GEMM forward / input gradient, HIP wgrad straight into the fp32 grads; in bf16 training mode

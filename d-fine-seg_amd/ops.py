@@ -350,7 +350,7 @@ class _DepthwiseConv2d(torch.autograd.Function):
     """Channel-last depthwise conv; see include/dfine_hip.h (dfine_dwconv_*)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride):
+    def forward(ctx, x, weight, stride, stats=None):
         _lib.require_gpu(x, weight)
         lib = _lib.load()
         B, C, H, W = x.shape
@@ -364,7 +364,7 @@ class _DepthwiseConv2d(torch.autograd.Function):
         y = torch.empty(B, OH, OW, C, dtype=xl.dtype, device=x.device)
         with _lib.timed("dwconv_fwd", (xl.numel() + y.numel()) * xl.element_size() + w.numel() * 4):
             rc = lib.dfine_dwconv_fwd(_lib.ptr(xl), _lib.ptr(w), _lib.ptr(y), _lib.dtype_code(xl),
-                                      B, H, W, C, k, stride, _lib.stream_ptr())
+                                      B, H, W, C, k, stride, _lib.ptr(stats), _lib.stream_ptr())
         _lib.check(rc, "dfine_dwconv_fwd")
         ctx.save_for_backward(xl, w)
         ctx.cfg = (stride, k, weight.dtype)
@@ -403,17 +403,23 @@ class _DepthwiseConv2d(torch.autograd.Function):
                                                  B, H, W, C, k, stride, st)
             _lib.check(rc, "dfine_dwconv_bwd_weight")
             dw = None if direct else dw.to(w_dtype)
-        return dx, dw, None
+        return dx, dw, None, None
 
 
-def depthwise_conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1) -> torch.Tensor:
+def depthwise_conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, stats=None) -> torch.Tensor:
     """MI355X replacement for ``F.conv2d(x, weight, None, stride, (k-1)//2, 1, groups=C)`` with
     ``weight`` [C, 1, k, k] (k in {3, 5}): x [B, C, H, W] in channels_last memory (float32 or
     bfloat16) -> y [B, C, OH, OW] channels_last, same dtype. The fp32 master weight is read
-    directly (no autocast cast)."""
+    directly (no autocast cast). ``stats`` (stride 1 only): as in ``dense_conv`` -- the kernel's epilogue leaves the
+    following BatchNorm's statistics in it."""
     if x.dtype not in (torch.float32, torch.bfloat16):
         x = x.float()
-    return _DepthwiseConv2d.apply(x, weight, int(stride))
+    return _DepthwiseConv2d.apply(x, weight, int(stride), stats)
+
+
+def depthwise_stats_supported(stride):
+    """Whether ``depthwise_conv2d`` can fill ``stats`` (the stride-1 strip kernel has the epilogue)."""
+    return int(stride) == 1 and _os.environ.get("DFINE_DWCONV_NO_STRIP") is None
 
 
 _ACT_CODES = {None: 0, "relu": 1, "silu": 2}

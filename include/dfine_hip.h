@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 11
+#define DFINE_ABI_VERSION 12
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -123,9 +123,12 @@ int dfine_go_union(const int32_t* gt_of_query, int32_t* go, int H, int B, int Q,
  *   w  [C, k, k] f32   (nn.Conv2d weight [C,1,k,k], fp32 master copy)
  *   dw [C, k, k] f32   ACCUMULATED with float atomics: the caller zeroes it
  * Supported: k in {3,5}, stride in {1,2}, C % 8 == 0 (bf16) / C % 4 == 0 (f32).
+  *   stats (forward, stride 1 only; or NULL): f64 [8][2][C], ACCUMULATED -- per channel the sum and the sum of squares of the
+ *   rounded outputs in the 8-replica layout dfine_bn_act_fwd reads (as dfine_igemm_bf16 does for dense convs), so the
+ *   BatchNorm behind a depthwise conv needs no statistics pass.
  * ------------------------------------------------------------------------------------- */
 int dfine_dwconv_fwd(const void* x, const float* w, void* y, int dtype, int B, int H, int W, int C,
-                     int k, int stride, void* stream);
+                     int k, int stride, double* stats, void* stream);
 int dfine_dwconv_bwd_data(const void* dy, const float* w, void* dx, int dtype, int B, int H, int W,
                           int C, int k, int stride, void* stream);
 /* workspace: f32 scratch of at least dfine_dwconv_bwd_weight_workspace(...) floats (per-block partial

@@ -49,3 +49,23 @@ def test_unsupported_shapes_fail_loudly(hip_lib):
     w = torch.randn(12, 1, 3, 3, device="cuda")
     with pytest.raises(_lib.DfineHipError):
         ops.depthwise_conv2d(x, w, 1)  # C % 8 != 0 for bf16
+
+
+@pytest.mark.parametrize("B,C,H,W,k", [(2, 128, 40, 40, 5), (3, 64, 21, 37, 5), (1, 32, 7, 5, 3), (2, 256, 20, 20, 5)])
+def test_statistics_epilogue_of_the_strip_kernel(hip_lib, B, C, H, W, k):
+    """dfine_dwconv_fwd with `stats`: per channel the sum and sum of squares of the bf16-ROUNDED outputs, spread over 8 fp64
+    replicas -- exactly what a statistics pass over y would give (1e-6 relative: fp32 partials inside a workgroup)."""
+    from dfine_seg_amd import ops
+
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(C, 1, k, k, generator=g) / k).cuda()
+    ws = torch.zeros(34 * C, device="cuda")
+    with torch.no_grad():
+        y = ops.depthwise_conv2d(x, w, 1, stats=ws[: 32 * C])
+        y_plain = ops.depthwise_conv2d(x, w, 1)
+    assert torch.equal(y, y_plain)
+    sums = ws[: 32 * C].view(torch.float64).view(8, 2, C).sum(0)
+    yd = y.double()
+    torch.testing.assert_close(sums[0], yd.sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(sums[1], (yd * yd).sum((0, 2, 3)), rtol=1e-5, atol=1e-3)

@@ -127,7 +127,7 @@ class _StockOps:
         ops.dense_conv_pair = lambda x, wa, wb, pa, pb, sa=None, sb=None: (F.conv2d(x, wa, None, 1, pa), F.conv2d(x, wb, None, 1, pb))
         ops.dense_conv = lambda x, w, stride=1, padding=0, pad_br=None, stats=None, out=None: F.conv2d(
             F.pad(x, (0, pad_br, 0, pad_br)) if pad_br else x, w, None, stride, padding)
-        ops.depthwise_conv2d = lambda x, w, stride=1: F.conv2d(x, w, None, stride, (w.shape[-1] - 1) // 2, 1, x.shape[1])
+        ops.depthwise_conv2d = lambda x, w, stride=1, stats=None: F.conv2d(x, w, None, stride, (w.shape[-1] - 1) // 2, 1, x.shape[1])
         ops.stem_pool_supported = lambda x: False
         ops.add_layer_norm_supported = lambda x, d: False
         ops.linear = lambda x, w, b=None, r0=0, r1=None, relu=False: (F.relu if relu else (lambda t: t))(
