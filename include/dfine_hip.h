@@ -292,7 +292,7 @@ int dfine_wgrad_group_launch(const void* table_host, const void* table_dev, void
  *     stat     = (top-k values of p in descending order, their mean)     prob.topk(k) ++ mean
  *   corners f32 [rows, 4, n_bins], ref_boxes f32 [rows, 4] (cxcywh), W f32 [n_bins]
  *   boxes f32 [rows, 4], stat f32 [rows, 4, k+1], top_idx u8 [rows, 4, k] (bins of the top-k, kept
- *   for the backward). k must be 4 (LQE(4, ...), :598); 4 <= n_bins <= 255.
+ *   for the backward). k must be 4 (LQE(4, ...), :598); 4 <= n_bins <= 60 (a workgroup holds 256 rows of n_bins logits in LDS so that global accesses are coalesced).
  * Backward: g_boxes f32 [rows, 4] and g_stat f32 [rows, 4, k+1] (either may be NULL = zero)
  *   -> g_corners f32 [rows, 4, n_bins] (written, not accumulated). ref_boxes and W get no gradient
  *   (the decoder detaches the reference boxes; up / reg_scale are frozen Parameters, :592-593).
