@@ -372,6 +372,18 @@ static int ig_launch(const void* A, const void* Bw, void* C, const float* bias, 
 template <int BK, int VEC, int OVEC, bool GATHER>
 static int ig_dispatch_n(const void* A, const void* Bw, void* C, const float* bias, double* stats, const IGemmGeom& g,
                          hipStream_t stream) {
+  // a problem with fewer output tiles than CUs (the 20x20 maps: 100 row tiles) runs on part of the chip: narrower N tiles
+  // multiply the workgroups at no HBM cost (the extra A reads hit L2); DFINE_IGEMM_FILL=0 switches it off
+  static const bool fill = !(getenv("DFINE_IGEMM_FILL") && atoi(getenv("DFINE_IGEMM_FILL")) == 0);
+  if (fill) {
+    const long long m_tiles = (g.M + 127) / 128;
+    int bn = ig_tile_n(g.N);
+    while (bn > 32 && m_tiles * ((g.N + bn - 1) / bn) < 200) bn >>= 1;
+    if (bn != ig_tile_n(g.N)) {
+      if (bn == 64) return ig_launch<2, BK, VEC, OVEC, GATHER>(A, Bw, C, bias, stats, g, stream);
+      return ig_launch<1, BK, VEC, OVEC, GATHER>(A, Bw, C, bias, stats, g, stream);
+    }
+  }
   switch (ig_tile_n(g.N)) {
     case 128: return ig_launch<4, BK, VEC, OVEC, GATHER>(A, Bw, C, bias, stats, g, stream);
     case 64: return ig_launch<2, BK, VEC, OVEC, GATHER>(A, Bw, C, bias, stats, g, stream);
