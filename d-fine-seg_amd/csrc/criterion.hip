@@ -17,6 +17,9 @@ struct CritArgs {
   int has_local, has_ddf;   // corners present / teacher present
   float alpha, gamma;       // varifocal
   float reg_scale, temp;    // FDR reg_scale, DDF temperature
+  // elements between consecutive images of each INPUT (rows of an image are dense): the decoder's outputs are [B, Nd + Q, .]
+  // and the heads are given the [:, :Nd] / [:, Nd:] halves in place instead of contiguous copies
+  long long sb_logits, sb_boxes, sb_corners, sb_ref, sb_tcorners, sb_tlogits;
 };
 
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
@@ -98,10 +101,20 @@ __global__ __launch_bounds__(256) void criterion_head_kernel(
   const int row = blockIdx.x * 4 + wave;  // (b, q)
   float t_vfl = 0.f, t_l1 = 0.f, t_giou = 0.f, t_fgl = 0.f, t_ddf = 0.f;
   if (row < a.B * a.Q) {
-    const int b = row / a.Q;
+    const int b = row / a.Q, q = row - b * a.Q;
+    logits += (size_t)b * a.sb_logits + (size_t)q * a.C;  // this row's inputs; outputs stay dense [B * Q, .]
+    boxes += (size_t)b * a.sb_boxes + (size_t)q * 4;
+    if (a.has_local) {
+      corners += (size_t)b * a.sb_corners + (size_t)q * 4 * a.NB;
+      ref += (size_t)b * a.sb_ref + (size_t)q * 4;
+    }
+    if (a.has_ddf) {
+      teacher_corners += (size_t)b * a.sb_tcorners + (size_t)q * 4 * a.NB;
+      teacher_logits += (size_t)b * a.sb_tlogits + (size_t)q * a.C;
+    }
     const float inv_nb_cls = scal[0] * scal[4];  // weight_dict["loss_vfl"] / num_boxes
     const float inv_nb_l1 = scal[1] * scal[5], inv_nb_giou = scal[1] * scal[6], inv_nb_fgl = scal[1] * scal[7];
-    const float4 pb = *reinterpret_cast<const float4*>(boxes + (size_t)row * 4);
+    const float4 pb = *reinterpret_cast<const float4*>(boxes);
     const Box pxy = to_xyxy(pb);
     // ---------------------------------------------------------------- varifocal (own matching)
     {
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(256) void criterion_head_kernel(
       }
       float acc = 0.f;
       for (int c = lane; c < a.C; c += 64) {
-        const float x = VecTraits<T>::load1(logits + (size_t)row * a.C + c);
+        const float x = VecTraits<T>::load1(logits + c);
         const float p = 1.f / (1.f + __expf(-x));
         const bool hit = c == label;
         const float t = hit ? iou : 0.f;
@@ -149,12 +162,12 @@ __global__ __launch_bounds__(256) void criterion_head_kernel(
       float w_ddf = iou;  // DDF weight: IoU where matched, else the teacher's best class probability
       if (a.has_ddf && !matched) {
         float mx = -INFINITY;
-        for (int c = lane; c < a.C; c += 64) mx = fmaxf(mx, VecTraits<T>::load1(teacher_logits + (size_t)row * a.C + c));
+        for (int c = lane; c < a.C; c += 64) mx = fmaxf(mx, VecTraits<T>::load1(teacher_logits + c));
         mx = wave_max(mx);
         w_ddf = 1.f / (1.f + __expf(-mx));
       }
       const float ddf_coef = (matched ? scal[2] : scal[3]) * scal[8];
-      const float4 rp = *reinterpret_cast<const float4*>(ref + (size_t)row * 4);
+      const float4 rp = *reinterpret_cast<const float4*>(ref);
       const float rs = a.reg_scale;
       const float wq = rp.z / rs + 1e-16f, hq = rp.w / rs + 1e-16f;
       const float dist[4] = {(rp.x - txy.x0) / wq - 0.5f * rs, (rp.y - txy.y0) / hq - 0.5f * rs,
@@ -165,8 +178,9 @@ __global__ __launch_bounds__(256) void criterion_head_kernel(
       const float temp = a.temp, inv_T = 1.f / a.temp;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const size_t off = ((size_t)row * 4 + e) * a.NB + lane;
-        const float x = live ? corners[off] : -INFINITY;
+        const size_t off = ((size_t)row * 4 + e) * a.NB + lane;  // dense outputs
+        const size_t in_off = (size_t)e * a.NB + lane;           // this row's inputs
+        const float x = live ? corners[in_off] : -INFINITY;
         const float mx = wave_max(x);
         const float ex = live ? __expf(x - mx) : 0.f;
         const float se = wave_sum(ex);
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(256) void criterion_head_kernel(
         }
         if (live) d_corners_fgl[off] = g_fgl;
         if (a.has_ddf) {
-          const float tc = live ? teacher_corners[off] : -INFINITY;
+          const float tc = live ? teacher_corners[in_off] : -INFINITY;
           const float es = live ? __expf((x - mx) * inv_T) : 0.f;  // student at temperature T (same max)
           const float ss = wave_sum(es);
           const float tmx = wave_max(tc);
@@ -228,7 +242,7 @@ extern "C" int dfine_criterion_head(const void* logits, int logits_dtype, const 
                                     const float* tgt_boxes, const float* Wn, const float* scalars, float* terms,
                                     void* d_logits, float* d_boxes_l1, float* d_boxes_giou, float* d_corners_fgl,
                                     float* d_corners_ddf, int B, int Q, int C, int G, int n_bins, float alpha,
-                                    float gamma, float reg_scale, float temperature, void* stream) {
+                                    float gamma, float reg_scale, float temperature, const long long* batch_strides, void* stream) {
   if (!logits || !boxes || !own_assign || !go_assign || !tgt_labels || !tgt_boxes || !scalars || !terms || !d_logits ||
       !d_boxes_l1 || !d_boxes_giou)
     return DFINE_E_BADARG;
@@ -237,7 +251,16 @@ extern "C" int dfine_criterion_head(const void* logits, int logits_dtype, const 
   const int has_ddf = has_local && teacher_corners != nullptr;
   if (has_local && (!ref_points || !Wn || !d_corners_fgl || n_bins <= 1 || n_bins > 64)) return DFINE_E_BADARG;
   if (has_ddf && (!teacher_logits || !d_corners_ddf)) return DFINE_E_BADARG;
-  CritArgs a{B, Q, C, G, n_bins, has_local, has_ddf, alpha, gamma, reg_scale, temperature};
+  CritArgs a{B, Q, C, G, n_bins, has_local, has_ddf, alpha, gamma, reg_scale, temperature,
+             (long long)Q * C, (long long)Q * 4, (long long)Q * 4 * n_bins, (long long)Q * 4, (long long)Q * 4 * n_bins, (long long)Q * C};
+  if (batch_strides) {  // logits, boxes, corners, ref_points, teacher_corners, teacher_logits (0 = dense)
+    long long* sb[6] = {&a.sb_logits, &a.sb_boxes, &a.sb_corners, &a.sb_ref, &a.sb_tcorners, &a.sb_tlogits};
+    for (int i = 0; i < 6; ++i) {
+      if (batch_strides[i] < 0 || (batch_strides[i] > 0 && batch_strides[i] < *sb[i])) return DFINE_E_BADARG;
+      if (batch_strides[i] > 0) *sb[i] = batch_strides[i];
+    }
+    if (a.sb_boxes % 4 != 0 || (has_local && a.sb_ref % 4 != 0)) return DFINE_E_UNSUPPORTED;  // float4 loads
+  }
   const int rows = B * Q;
   dim3 grid((rows + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;

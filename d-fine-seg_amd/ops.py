@@ -657,28 +657,42 @@ class _CriterionHead(torch.autograd.Function):
         dev = logits.device
         if logits.dtype not in (torch.float32, torch.bfloat16):
             logits = logits.float()
-        logits, boxes = logits.contiguous(), boxes.float().contiguous()
+        strides = [0] * 6  # elements between images of each input, 0 = dense (dfine_criterion_head batch_strides)
+
+        def rows(t, slot, dtype=None):
+            """[B, Q, W] input as the kernel reads it: the [:, a:b] part of a wider decoder output stays in place (dense rows
+            per image, a batch stride), anything else becomes a dense copy."""
+            if dtype is not None and t.dtype != dtype:
+                t = t.to(dtype)
+            Wd = t.shape[-1]
+            if t.dim() == 3 and t.stride(2) == 1 and t.stride(1) == Wd and t.stride(0) >= t.shape[1] * Wd and (
+                    t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 or slot not in (1, 3)):
+                strides[slot] = t.stride(0)
+                return t
+            return t.contiguous()
+
+        logits, boxes = rows(logits, 0), rows(boxes, 1, torch.float32)
         has_local = corners is not None
         has_ddf = has_local and teacher_corners is not None
         n_bins = corners.shape[-1] // 4 if has_local else 0
         if has_local:
-            corners, ref_points = corners.float().contiguous(), ref_points.float().contiguous()
+            corners, ref_points = rows(corners, 2, torch.float32), rows(ref_points, 3, torch.float32)
         if has_ddf:
-            teacher_corners = teacher_corners.float().contiguous()
-            teacher_logits = teacher_logits.to(logits.dtype).contiguous()
+            teacher_corners = rows(teacher_corners, 4, torch.float32)
+            teacher_logits = rows(teacher_logits, 5, logits.dtype)
         terms = zeros_f32(64 * 8, dev)  # 64 replicas of the five sums (see dfine_criterion_head)
-        d_logits = torch.empty_like(logits)
+        d_logits = torch.empty(logits.shape, dtype=logits.dtype, device=dev)  # outputs are dense whatever the inputs' pitch
         d_l1 = torch.empty(B, Q, 4, dtype=torch.float32, device=dev)
         d_giou = torch.empty_like(d_l1)
-        d_fgl = torch.empty_like(corners) if has_local else None
-        d_ddf = torch.empty_like(corners) if has_ddf else None
+        d_fgl = torch.empty(corners.shape, dtype=torch.float32, device=dev) if has_local else None
+        d_ddf = torch.empty(corners.shape, dtype=torch.float32, device=dev) if has_ddf else None
         with _lib.timed("criterion_head", logits.numel() * logits.element_size() * 2 + (corners.numel() * 16 if has_local else 0)):
             rc = lib.dfine_criterion_head(
                 _lib.ptr(logits), _lib.dtype_code(logits), _lib.ptr(boxes), _lib.ptr(corners), _lib.ptr(ref_points),
                 _lib.ptr(teacher_corners) if has_ddf else None, _lib.ptr(teacher_logits) if has_ddf else None,
                 _lib.ptr(own), _lib.ptr(go), _lib.ptr(tgt_labels), _lib.ptr(tgt_boxes), _lib.ptr(Wn), _lib.ptr(scalars),
                 _lib.ptr(terms), _lib.ptr(d_logits), _lib.ptr(d_l1), _lib.ptr(d_giou), _lib.ptr(d_fgl), _lib.ptr(d_ddf),
-                B, Q, C, G, n_bins, alpha, gamma, reg_scale, temperature, _lib.stream_ptr())
+                B, Q, C, G, n_bins, alpha, gamma, reg_scale, temperature, (ctypes.c_longlong * 6)(*strides), _lib.stream_ptr())
         _lib.check(rc, "dfine_criterion_head")
         ctx.save_for_backward(d_logits, d_l1, d_giou, d_fgl, d_ddf)
         ctx.mark_non_differentiable()

@@ -275,7 +275,7 @@ class TrainStep:
         # backward is now one HIP kernel (ops.embedding) and that pipeline is no longer on the path
         if not self.use_graph or self.iters <= self.graph_warmup or (tb.mask_tgt is not None and not self.graph_masks):
             self.last_step_replayed = False
-            return self._body(images, tb, inject)
+            return self._body(self._model_input(images), tb, inject)
         leaves = self._inject_leaves(inject)
         key = (tuple(images.shape), tb.max_gt, max(tb.num_gts), tb.total > 0, tb.mask_tgt is not None,
                tuple((path, tuple(t.shape)) for path, t in leaves))
@@ -303,6 +303,13 @@ class TrainStep:
             m._pending_batches += 1
         return s_loss
 
+    def _model_input(self, images):
+        """The image batch as the stem's implicit GEMM reads it: bf16 under autocast (the conv casts its input anyway; doing it
+        here makes the replay path's copy into the static buffer the one and only cast kernel)."""
+        if self.amp and images.dtype == torch.float32:
+            return images.to(torch.bfloat16)
+        return images
+
     def _capture(self, images, tb, inject=None):
         """See ``_capture_impl``. Python's cyclic GC is held off for the duration: a hipGraph object of an earlier TrainStep
         (or any other tensor-owning cycle) finalised in the middle of a capture calls hipGraphDestroy / hipFree while the
@@ -327,7 +334,7 @@ class TrainStep:
         """Capture the step for this (batch shape, padded GT width, max GT count). The per-image GT
         counts inside may vary between replays; the maximum (it fixes the number of denoising
         queries) may not -- a new maximum gets its own graph."""
-        s_images = images.clone()
+        s_images = self._model_input(images).clone()  # bf16 under autocast: the per-replay copy into it is the ONLY cast
         s_tb = TargetBatch(tb.labels.clone(), tb.boxes.clone(), tb.valid.clone(), list(tb.num_gts), tb.counts.clone(), None,
                            tb.mask_tgt.clone() if tb.mask_tgt is not None else None)
         s_leaves = [(path, t.to(self.device).clone()) for path, t in self._inject_leaves(inject)]

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 12
+#define DFINE_ABI_VERSION 13
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -213,6 +213,9 @@ int dfine_adamw_ema_step(float* param, float* grad, float* exp_avg, float* exp_a
  *       ACCUMULATED (caller zeroes, and sums the replicas)
  *   d_logits [B,Q,C] (logits dtype), d_boxes_l1 / d_boxes_giou [B,Q,4], d_corners_fgl / d_corners_ddf
  *       [B,Q,4*n_bins] f32: gradient of the corresponding weighted term (overwritten)
+  *   batch_strides (HOST pointer to 6 values, or NULL): elements between consecutive images of logits, boxes, corners,
+ *   ref_points, teacher_corners, teacher_logits (0 = dense). The rows of one image must be dense; with a stride a head can
+ *   be given the [:, :Nd] / [:, Nd:] part of a [B, Nd + Q, .] decoder output in place. Outputs are always dense.
  * ------------------------------------------------------------------------------------- */
 int dfine_criterion_head(const void* logits, int logits_dtype, const float* boxes, const float* corners,
                          const float* ref_points, const float* teacher_corners, const void* teacher_logits,
@@ -220,7 +223,7 @@ int dfine_criterion_head(const void* logits, int logits_dtype, const float* boxe
                          const float* tgt_boxes, const float* Wn, const float* scalars, float* terms,
                          void* d_logits, float* d_boxes_l1, float* d_boxes_giou, float* d_corners_fgl,
                          float* d_corners_ddf, int B, int Q, int C, int G, int n_bins, float alpha, float gamma,
-                         float reg_scale, float temperature, void* stream);
+                         float reg_scale, float temperature, const long long* batch_strides, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Weight/bias gradient of y = x @ W^T + b (autograd of F.linear / nn.Linear, used by every

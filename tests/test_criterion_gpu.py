@@ -94,3 +94,38 @@ def test_fused_heads_match_dense_formulation(hip_lib, counts, dtype):
         assert (ga is None) == (gb is None), i
         if ga is not None:
             torch.testing.assert_close(gb, ga, **tol, msg=lambda m: f"leaf {i} {tuple(ga.shape)}: {m}")
+
+
+@pytest.mark.gpu
+def test_head_reads_slices_of_a_wider_decoder_output_in_place(hip_lib):
+    """The decoder's outputs are [B, Nd + Q, .]; a head gets the [:, :Nd] or [:, Nd:] part as a strided view
+    (dfine_criterion_head batch_strides) instead of a contiguous copy: loss terms and gradients bit-equal to the dense call."""
+    from dfine_seg_amd import ops
+
+    torch.manual_seed(3)
+    B, Nd, Q, C, G, NB = 3, 40, 60, 80, 7, 33
+    dev = "cuda"
+    full_logits = torch.randn(B, Nd + Q, C, device=dev).bfloat16()
+    full_boxes = torch.rand(B, Nd + Q, 4, device=dev) * 0.5 + 0.2
+    full_corners = torch.randn(B, Nd + Q, 4 * NB, device=dev)
+    full_ref = torch.rand(B, Nd + Q, 4, device=dev) * 0.5 + 0.2
+    t_corners, t_logits = torch.randn_like(full_corners), torch.randn_like(full_logits)
+    labels = torch.randint(0, C, (B, G), device=dev)
+    tboxes = torch.rand(B, G, 4, device=dev) * 0.4 + 0.3
+    Wn = torch.linspace(-2, 2, NB, device=dev)
+    scal = torch.tensor([0.1, 0.1, 0.01, 0.02, 1.0, 5.0, 2.0, 0.15, 1.5], device=dev)
+    for lo, hi in ((0, Nd), (Nd, Nd + Q)):
+        n = hi - lo
+        own = torch.randint(-1, G, (B, n), device=dev, dtype=torch.int32)
+        outs = []
+        for dense in (True, False):
+            sl = lambda t: (t[:, lo:hi].contiguous() if dense else t[:, lo:hi]).detach().requires_grad_(t.is_floating_point())
+            lg, bx, cr = sl(full_logits), sl(full_boxes), sl(full_corners)
+            terms = ops.criterion_head(lg, bx, cr, full_ref[:, lo:hi] if not dense else full_ref[:, lo:hi].contiguous(),
+                                       t_corners[:, lo:hi] if not dense else t_corners[:, lo:hi].contiguous(),
+                                       t_logits[:, lo:hi] if not dense else t_logits[:, lo:hi].contiguous(),
+                                       own, own, labels, tboxes, Wn, scal)
+            torch.stack(terms).sum().backward()
+            outs.append((torch.stack(terms).detach(), lg.grad, bx.grad, cr.grad))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
