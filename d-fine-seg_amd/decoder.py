@@ -91,6 +91,9 @@ class MSDeformableAttention(nn.Module):
         return ops.deformable_attention_core(value, spatial_shapes, loc, weights, self.num_points, sink, finalize)
 
 
+_FUSED_GATE = True  # tests flip it to compare with the op-by-op form
+
+
 class Gate(nn.Module):
     def __init__(self, dim):
         super().__init__()
@@ -100,7 +103,10 @@ class Gate(nn.Module):
         self.norm = LayerNorm(dim)
 
     def forward(self, a, b):
-        g1, g2 = torch.sigmoid(self.gate(torch.cat([a, b], -1))).chunk(2, -1)
+        pre = self.gate(torch.cat([a, b], -1))
+        if a.is_cuda and pre.dtype == a.dtype == b.dtype and pre.dtype in (torch.float32, torch.bfloat16) and _FUSED_GATE:
+            return self.norm(ops.gate_mix(pre, a, b))  # sigmoid, both products and their backward: one launch each way
+        g1, g2 = torch.sigmoid(pre).chunk(2, -1)
         return self.norm(g1 * a, g2 * b)
 
 

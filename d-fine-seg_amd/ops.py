@@ -823,6 +823,42 @@ def upsample_nearest2x_supported(x):
     return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0
 
 
+class _GateMix(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pre, a, b):
+        lib = _lib.load()
+        D = a.shape[-1]
+        pre, a, b = pre.contiguous(), a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        rc = lib.dfine_gate_mix_fwd(_lib.ptr(pre), _lib.ptr(a), _lib.ptr(b), _lib.dtype_code(a), _lib.ptr(out), a.numel() // D, D,
+                                    _lib.stream_ptr())
+        _lib.check(rc, "dfine_gate_mix_fwd")
+        ctx.save_for_backward(pre, a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pre, a, b = ctx.saved_tensors
+        lib = _lib.load()
+        D = a.shape[-1]
+        g = g.to(a.dtype).contiguous()
+        dpre, da, db = torch.empty_like(pre), torch.empty_like(a), torch.empty_like(b)
+        rc = lib.dfine_gate_mix_bwd(_lib.ptr(pre), _lib.ptr(a), _lib.ptr(b), _lib.ptr(g), _lib.dtype_code(a), _lib.ptr(dpre), _lib.ptr(da),
+                                    _lib.ptr(db), a.numel() // D, D, _lib.stream_ptr())
+        _lib.check(rc, "dfine_gate_mix_bwd")
+        return dpre, da, db
+
+
+def gate_mix(pre, a, b):
+    """``g1 * a + g2 * b`` with ``g1, g2 = sigmoid(pre).chunk(2, -1)`` (the decoder gateway between its Linear and its
+    LayerNorm, dfine_decoder.py:181-196): one HIP launch forward, one backward, on the GPU for bf16 / fp32 of one dtype."""
+    if (a.is_cuda and a.dtype in (torch.float32, torch.bfloat16) and pre.dtype == a.dtype == b.dtype
+            and pre.shape[-1] == 2 * a.shape[-1] and a.shape == b.shape):
+        return _GateMix.apply(pre, a, b)
+    g1, g2 = torch.sigmoid(pre).chunk(2, -1)
+    return g1 * a + g2 * b
+
+
 def row_max(x):
     """``x.max(-1).values`` as float32 for a dense bf16 / fp32 CUDA tensor, one HIP launch (query selection's best class
     logit per token); not differentiable. Anything else goes to ATen."""

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 13
+#define DFINE_ABI_VERSION 14
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -368,6 +368,17 @@ int dfine_add_layernorm_fwd(const void* x, const void* res, int dtype, const flo
 int dfine_add_layernorm_bwd(const void* dy, const void* s, int dtype, const float* gamma, const float* mean,
                             const float* rstd, void* ds, float* dgamma, float* dbeta, long long M, int D, float clamp,
                             void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Elementwise middle of the decoder layer's gateway (reference src/d_fine/arch/dfine_decoder.py:181-196 Gate:
+ * gates = sigmoid(Linear(cat(a, b))); out = norm(gate1 * a + gate2 * b)), forward and backward, one launch each:
+ *     mix[m][d] = sigmoid(pre[m][d]) * a[m][d] + sigmoid(pre[m][D + d]) * b[m][d]
+ *   pre [M, 2D] (the Linear's output), a, b, mix, g (= d mix), da, db [M, D], dpre [M, 2D]; bf16 or f32, dense.
+ *   Factors and products are rounded to the tensor dtype like the separate ops' outputs.
+ * ------------------------------------------------------------------------------------- */
+int dfine_gate_mix_fwd(const void* pre, const void* a, const void* b, int dtype, void* out, long long M, int D, void* stream);
+int dfine_gate_mix_bwd(const void* pre, const void* a, const void* b, const void* g, int dtype, void* dpre, void* da, void* db,
+                       long long M, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / Linear, forward and input gradient, bf16 MFMA with fp32 accumulation:

@@ -60,3 +60,29 @@ def test_add_layer_norm_unsupported_width(hip_lib):
     z = torch.zeros(4 * 320, device="cuda")
     assert hip_lib.dfine_add_layernorm_fwd(_lib.ptr(z), None, 0, _lib.ptr(z), _lib.ptr(z), _lib.ptr(z), None, _lib.ptr(z), _lib.ptr(z),
                                            4, 320, 1e-5, 0.0, None) == -2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gate_mix_matches_the_op_by_op_gateway(hip_lib, dtype):
+    """ops.gate_mix (dfine_gate_mix_fwd / _bwd) vs sigmoid(pre).chunk -> g1 * a + g2 * b with autograd, same dtype:
+    fp32 to 1e-6; bf16 within one rounding of the op-by-op form (which rounds sigmoid, products and the sum to bf16 too)."""
+    from dfine_seg_amd import ops
+
+    torch.manual_seed(0)
+    M, D = 1000, 256
+    pre = torch.randn(4, M // 4, 2 * D, device="cuda").to(dtype).requires_grad_(True)
+    a = torch.randn(4, M // 4, D, device="cuda").to(dtype).requires_grad_(True)
+    b = torch.randn(4, M // 4, D, device="cuda").to(dtype).requires_grad_(True)
+    g = torch.randn(4, M // 4, D, device="cuda").to(dtype)
+    out = ops.gate_mix(pre, a, b)
+    out.backward(g)
+    got = (out.detach(), pre.grad, a.grad, b.grad)
+    pre2, a2, b2 = (t.detach().clone().requires_grad_(True) for t in (pre, a, b))
+    g1, g2 = torch.sigmoid(pre2).chunk(2, -1)
+    ref_out = g1 * a2 + g2 * b2
+    ref_out.backward(g)
+    ref = (ref_out.detach(), pre2.grad, a2.grad, b2.grad)
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    for x, y in zip(got, ref):
+        torch.testing.assert_close(x.float(), y.float(), **tol)
