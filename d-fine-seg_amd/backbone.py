@@ -22,7 +22,15 @@ class Stem(nn.Module):
         self.stem4 = ConvNorm(c_mid, c_out, 1, **kw)
 
     def forward(self, x):
-        u = self.stem1(x)
+        if x.shape[1] == 4 and self.stem1.conv.in_channels == 3 and not hasattr(self.stem1, "conv_bn_fused"):
+            # the image arrives zero-padded to 4 channels (TrainStep does, on the bf16 path): 8-byte tap loads in the implicit
+            # GEMM and its weight gradient instead of 2-byte ones. The PARAMETER keeps its [24, 3, 3, 3] shape: the padded
+            # copy is a differentiable view of it (pad's backward slices the gradient back)
+            w4 = F.pad(self.stem1.conv.weight, (0, 0, 0, 0, 0, 1)).contiguous(memory_format=torch.channels_last)
+            y, ws, hs = self.stem1._conv(x, w4)
+            u = self.stem1._norm_tail(y, ws, hs)
+        else:
+            u = self.stem1(x)
         c = u.shape[1]
         if ops.stem_pool_supported(u) and ops.concat_buffer_supported(u, [c, c]) and u.dtype == torch.bfloat16:
             # pooled map and conv branch are written straight into the two halves of one buffer (no torch.cat on the largest

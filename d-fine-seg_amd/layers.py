@@ -127,8 +127,9 @@ class ConvNorm(nn.Module):
             return ops.bn_workspace(self.conv.out_channels, x.device), True
         return None, False
 
-    def _conv(self, x):
-        """The convolution alone -> (output, norm workspace, whether the workspace already holds the batch statistics)."""
+    def _conv(self, x, weight=None):
+        """The convolution alone -> (output, norm workspace, whether the workspace already holds the batch statistics).
+        ``weight``: a stand-in for ``conv.weight`` with the same geometry (the stem's weight zero-padded to 4 input channels)."""
         conv = self.conv
         ws, have_stats = None, False
         if conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1:
@@ -141,7 +142,7 @@ class ConvNorm(nn.Module):
             # HIP implicit-GEMM forward / input gradient, HIP wgrad straight into the fp32 grads; in bf16 training mode
             # the conv's epilogue leaves the BatchNorm statistics in the norm's workspace (no statistics pass)
             ws, have_stats = self._stats_workspace(x)
-            x = ops.dense_conv(x, conv.weight, conv.stride[0], conv.padding[0], self.pad_br,
+            x = ops.dense_conv(x, conv.weight if weight is None else weight, conv.stride[0], conv.padding[0], self.pad_br,
                                stats=ws[: 32 * conv.out_channels] if have_stats else None)
         else:
             if self.pad_br is not None:

@@ -11,6 +11,8 @@ otherwise bound by the ~9 000 kernel launches of the eager path, not by the GPU.
 import math
 from copy import deepcopy
 
+import os
+
 import torch
 
 from .dfine import build_loss, build_model
@@ -90,6 +92,9 @@ class _StagedGraph:
             self.reducer.reduce_stage(i)  # side stream: overlaps the next stage's replay
         self.reducer.join()
         self.tail.replay()
+
+
+PAD_IMAGE_CHANNELS = os.environ.get("DFINE_PAD_IMAGE", "1") != "0"  # bf16 path: feed the stem a 4-channel image
 
 
 class TrainStep:
@@ -291,7 +296,7 @@ class TrainStep:
         graph, s_images, s_tb, s_loss, s_leaves = entry
         for (_, dst), (_, src) in zip(s_leaves, leaves):
             dst.copy_(src, non_blocking=True)
-        s_images.copy_(images, non_blocking=True)
+        (s_images[:, :3] if s_images.shape[1] != images.shape[1] else s_images).copy_(images, non_blocking=True)
         s_tb.labels.copy_(tb.labels, non_blocking=True)
         s_tb.boxes.copy_(tb.boxes, non_blocking=True)
         s_tb.valid.copy_(tb.valid, non_blocking=True)
@@ -306,6 +311,12 @@ class TrainStep:
     def _model_input(self, images):
         """The image batch as the stem's implicit GEMM reads it: bf16 under autocast (the conv casts its input anyway; doing it
         here makes the replay path's copy into the static buffer the one and only cast kernel)."""
+        if self.amp and images.is_cuda and images.shape[1] == 3 and PAD_IMAGE_CHANNELS:
+            # ... and zero-padded to 4 channels (8-byte pixels): the stem's 3-channel gather is element-wise otherwise
+            B, _, H, W = images.shape
+            out = torch.zeros(B, H, W, 4, dtype=torch.bfloat16, device=images.device).permute(0, 3, 1, 2)
+            out[:, :3].copy_(images)
+            return out
         if self.amp and images.dtype == torch.float32:
             return images.to(torch.bfloat16)
         return images
