@@ -411,9 +411,96 @@ static int launch_bwd(const void* value, const float* loc, const float* attn,
   return 0;
 }
 
+// The glue in front of the gather (reference dfine_decoder.py:148-166): sampling locations from the offset projection and the
+// reference boxes, attention weights = softmax over the P points of a head -- one thread per (token, head), forward and
+// backward, instead of ~7 + ~10 elementwise launches per decoder layer:
+//     loc[p]  = ref.xy + off[p] * (scale[p] * 0.5) * ref.wh          w[p] = softmax_p(logit[p])
+//     d off[p] = d loc[p] * (scale[p] * 0.5) * ref.wh                d logit[p] = w[p] * (d w[p] - sum_q w[q] d w[q])
+// (the reference boxes are detached in the decoder, dfine_decoder.py:476: no gradient flows into them)
+template <typename T>
+__global__ __launch_bounds__(256) void msda_prepare_fwd_kernel(const T* __restrict__ off, const T* __restrict__ logit,
+                                                              const float* __restrict__ ref, const float* __restrict__ scale,
+                                                              float* __restrict__ loc, float* __restrict__ w, long long n_tok, int nH, int P) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (token, head)
+  if (t >= n_tok * nH) return;
+  const long long tok = t / nH;
+  const float4 r = *reinterpret_cast<const float4*>(ref + tok * 4);
+  const T* o = off + t * P * 2;
+  const T* lg = logit + t * P;
+  float m = -INFINITY;
+  for (int p = 0; p < P; ++p) m = fmaxf(m, VecTraits<T>::load1(lg + p));
+  float sum = 0.f;
+  for (int p = 0; p < P; ++p) sum += __expf(VecTraits<T>::load1(lg + p) - m);
+  const float inv = 1.f / sum;
+  for (int p = 0; p < P; ++p) {
+    const float k = scale[p] * 0.5f;
+    loc[(t * P + p) * 2 + 0] = r.x + VecTraits<T>::load1(o + 2 * p) * k * r.z;
+    loc[(t * P + p) * 2 + 1] = r.y + VecTraits<T>::load1(o + 2 * p + 1) * k * r.w;
+    w[t * P + p] = __expf(VecTraits<T>::load1(lg + p) - m) * inv;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void msda_prepare_bwd_kernel(const float* __restrict__ g_loc, const float* __restrict__ g_w,
+                                                              const float* __restrict__ w, const float* __restrict__ ref,
+                                                              const float* __restrict__ scale, T* __restrict__ d_off,
+                                                              T* __restrict__ d_logit, long long n_tok, int nH, int P) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tok * nH) return;
+  const long long tok = t / nH;
+  const float4 r = *reinterpret_cast<const float4*>(ref + tok * 4);
+  float dot = 0.f;
+  for (int p = 0; p < P; ++p) dot += w[t * P + p] * g_w[t * P + p];
+  for (int p = 0; p < P; ++p) {
+    const float k = scale[p] * 0.5f;
+    store1(d_off + (t * P + p) * 2 + 0, g_loc[(t * P + p) * 2 + 0] * k * r.z);
+    store1(d_off + (t * P + p) * 2 + 1, g_loc[(t * P + p) * 2 + 1] * k * r.w);
+    store1(d_logit + t * P + p, w[t * P + p] * (g_w[t * P + p] - dot));
+  }
+}
+
 }  // namespace dfine
 
 using namespace dfine;
+
+extern "C" int dfine_msda_prepare_fwd(const void* offsets, const void* logits, int dtype, const float* ref_boxes, const float* point_scale,
+                                      float* loc, float* weights, long long n_tokens, int nH, int P, void* stream) {
+  if (!offsets || !logits || !ref_boxes || !point_scale || !loc || !weights) return DFINE_E_BADARG;
+  if (n_tokens <= 0 || nH <= 0 || P <= 0) return DFINE_E_BADARG;
+  const long long blocks = (n_tokens * nH + 255) / 256;
+  if (blocks > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DFINE_DT_BF16)
+    hipLaunchKernelGGL(msda_prepare_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)offsets, (const bf16_t*)logits,
+                       ref_boxes, point_scale, loc, weights, n_tokens, nH, P);
+  else if (dtype == DFINE_DT_F32)
+    hipLaunchKernelGGL(msda_prepare_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)offsets, (const float*)logits,
+                       ref_boxes, point_scale, loc, weights, n_tokens, nH, P);
+  else
+    return DFINE_E_UNSUPPORTED;
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dfine_msda_prepare_bwd(const float* grad_loc, const float* grad_weights, const float* weights, const float* ref_boxes,
+                                      const float* point_scale, int dtype, void* d_offsets, void* d_logits, long long n_tokens, int nH,
+                                      int P, void* stream) {
+  if (!grad_loc || !grad_weights || !weights || !ref_boxes || !point_scale || !d_offsets || !d_logits) return DFINE_E_BADARG;
+  if (n_tokens <= 0 || nH <= 0 || P <= 0) return DFINE_E_BADARG;
+  const long long blocks = (n_tokens * nH + 255) / 256;
+  if (blocks > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DFINE_DT_BF16)
+    hipLaunchKernelGGL(msda_prepare_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, grad_loc, grad_weights, weights, ref_boxes,
+                       point_scale, (bf16_t*)d_offsets, (bf16_t*)d_logits, n_tokens, nH, P);
+  else if (dtype == DFINE_DT_F32)
+    hipLaunchKernelGGL(msda_prepare_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, grad_loc, grad_weights, weights, ref_boxes,
+                       point_scale, (float*)d_offsets, (float*)d_logits, n_tokens, nH, P);
+  else
+    return DFINE_E_UNSUPPORTED;
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int dfine_abi_version(void) { return DFINE_ABI_VERSION; }
 

@@ -84,10 +84,7 @@ class MSDeformableAttention(nn.Module):
         """query [B,Lq,D]; ref_boxes [B,Lq,4] cxcywh; value [B,S,nH,c] channel-last memory."""
         B, Lq, _ = query.shape
         nH, P = self.n_head, sum(self.num_points)
-        offsets = self.sampling_offsets(query).float().view(B, Lq, nH, P, 2)
-        weights = torch.softmax(self.attention_weights(query).float().view(B, Lq, nH, P), dim=-1)
-        ref = ref_boxes.float()[:, :, None, None, :]
-        loc = ref[..., :2] + offsets * (self.num_points_scale.view(P, 1) * 0.5) * ref[..., 2:]
+        loc, weights = ops.msda_prepare(self.sampling_offsets(query), self.attention_weights(query), ref_boxes, self.num_points_scale, nH)
         return ops.deformable_attention_core(value, spatial_shapes, loc, weights, self.num_points, sink, finalize)
 
 

@@ -859,6 +859,61 @@ def gate_mix(pre, a, b):
     return g1 * a + g2 * b
 
 
+MSDA_PREPARE_FUSED = os.environ.get("DFINE_MSDA_PREPARE", "1") != "0"  # measurement switch
+
+
+class _MsdaPrepare(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, offsets, logits, ref_boxes, point_scale, n_head):
+        lib = _lib.load()
+        P = point_scale.numel()
+        n_tok = ref_boxes.numel() // 4
+        offsets, logits = offsets.contiguous(), logits.contiguous()
+        ref = ref_boxes.detach().float().contiguous()
+        scale = point_scale.float().contiguous()
+        lead = ref_boxes.shape[:-1]
+        loc = torch.empty(*lead, n_head, P, 2, dtype=torch.float32, device=offsets.device)
+        weights = torch.empty(*lead, n_head, P, dtype=torch.float32, device=offsets.device)
+        rc = lib.dfine_msda_prepare_fwd(_lib.ptr(offsets), _lib.ptr(logits), _lib.dtype_code(offsets), _lib.ptr(ref), _lib.ptr(scale),
+                                        _lib.ptr(loc), _lib.ptr(weights), n_tok, n_head, P, _lib.stream_ptr())
+        _lib.check(rc, "dfine_msda_prepare_fwd")
+        ctx.save_for_backward(weights, ref, scale)
+        ctx.meta = (offsets.shape, logits.shape, offsets.dtype, n_head, P, n_tok)
+        return loc, weights
+
+    @staticmethod
+    def backward(ctx, g_loc, g_w):
+        weights, ref, scale = ctx.saved_tensors
+        off_shape, logit_shape, dtype, n_head, P, n_tok = ctx.meta
+        lib = _lib.load()
+        g_loc = torch.zeros_like(weights).unsqueeze(-1).expand(*weights.shape, 2).contiguous() if g_loc is None else g_loc.float().contiguous()
+        g_w = torch.zeros_like(weights) if g_w is None else g_w.float().contiguous()
+        d_off = torch.empty(off_shape, dtype=dtype, device=weights.device)
+        d_logit = torch.empty(logit_shape, dtype=dtype, device=weights.device)
+        rc = lib.dfine_msda_prepare_bwd(_lib.ptr(g_loc), _lib.ptr(g_w), _lib.ptr(weights), _lib.ptr(ref), _lib.ptr(scale),
+                                        _lib.dtype_code(d_off), _lib.ptr(d_off), _lib.ptr(d_logit), n_tok, n_head, P, _lib.stream_ptr())
+        _lib.check(rc, "dfine_msda_prepare_bwd")
+        return d_off, d_logit, None, None, None
+
+
+def msda_prepare(offsets, logits, ref_boxes, point_scale, n_head):
+    """Sampling locations and attention weights of the deformable cross-attention from its two projections
+    (dfine_decoder.py:148-166): ``loc = ref.xy + offsets * (point_scale * 0.5) * ref.wh`` as float32 [..., nH, P, 2] and
+    ``softmax`` over the P points of each head as float32 [..., nH, P]. One HIP launch forward and one backward on the GPU when
+    the reference boxes carry no gradient (the decoder detaches them); the op-by-op form otherwise."""
+    P = point_scale.numel()
+    lead = ref_boxes.shape[:-1]
+    if (MSDA_PREPARE_FUSED and offsets.is_cuda and offsets.dtype in (torch.float32, torch.bfloat16) and offsets.dtype == logits.dtype
+            and ref_boxes.shape[-1] == 4 and not (torch.is_grad_enabled() and ref_boxes.requires_grad)
+            and offsets.numel() == ref_boxes.numel() // 4 * n_head * P * 2 and logits.numel() == ref_boxes.numel() // 4 * n_head * P):
+        return _MsdaPrepare.apply(offsets, logits, ref_boxes, point_scale, n_head)
+    off = offsets.float().view(*lead, n_head, P, 2)
+    weights = torch.softmax(logits.float().view(*lead, n_head, P), dim=-1)
+    ref = ref_boxes.float()[..., None, None, :]
+    loc = ref[..., :2] + off * (point_scale.view(P, 1) * 0.5) * ref[..., 2:]
+    return loc, weights
+
+
 def row_max(x):
     """``x.max(-1).values`` as float32 for a dense bf16 / fp32 CUDA tensor, one HIP launch (query selection's best class
     logit per token); not differentiable. Anything else goes to ATen."""

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 14
+#define DFINE_ABI_VERSION 15
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -82,6 +82,21 @@ int dfine_msda_bwd(const void* value, int value_dtype, const float* loc, const f
                    const void* grad_out, void* grad_value, int grad_value_dtype, float* grad_loc, float* grad_attn,
                    int B, int S, int Lq, int nH, int c, int n_levels, const int32_t* level_hw,
                    const int32_t* num_points, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * The elementwise glue in front of the gather (reference src/d_fine/arch/dfine_decoder.py:148-166 MSDeformableAttention.forward):
+ *     loc[tok][h][p]  = ref.xy + offsets[tok][h][p] * (point_scale[p] * 0.5) * ref.wh       (4-d reference boxes, cxcywh)
+ *     weights[tok][h] = softmax over the P points of the head's attention logits
+ * and its backward (d offsets, d logits from d loc, d weights), one launch each instead of ~7 + ~10 elementwise launches per
+ * decoder layer. offsets [n_tokens, nH, P, 2] and logits [n_tokens, nH, P] bf16 or f32 (the projections' outputs), ref_boxes
+ * f32 [n_tokens, 4], point_scale f32 [P]; loc f32 [n_tokens, nH, P, 2], weights f32 [n_tokens, nH, P]. No gradient for the
+ * reference boxes (the decoder detaches them, dfine_decoder.py:476).
+ * ------------------------------------------------------------------------------------- */
+int dfine_msda_prepare_fwd(const void* offsets, const void* logits, int dtype, const float* ref_boxes, const float* point_scale,
+                           float* loc, float* weights, long long n_tokens, int nH, int P, void* stream);
+int dfine_msda_prepare_bwd(const float* grad_loc, const float* grad_weights, const float* weights, const float* ref_boxes,
+                           const float* point_scale, int dtype, void* d_offsets, void* d_logits, long long n_tokens, int nH,
+                           int P, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Hungarian matching without leaving the device. Replaces HungarianMatcher.forward

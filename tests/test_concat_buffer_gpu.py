@@ -55,6 +55,12 @@ def test_hg_block_without_cat_matches_the_cat_path(hip_lib, monkeypatch, light, 
             # it out): the true gradient is 0 and every run holds nothing but round-off there
             assert float(g1[n].abs().max()) < 1.0
             continue
+        if rel(g0[n], gr[n]) > 0.5:
+            # the weights of the test loss sum to zero, so the true LAB bias gradient (the sum of ALL gradient elements) is ~0
+            # and both bf16 runs hold only cancellation noise there, whose size also depends on the atomics' order: same
+            # magnitude is all that can be asked
+            assert float((g1[n].float() - gr[n].float()).norm()) < 4 * float((g0[n].float() - gr[n].float()).norm()), n
+            continue
         assert rel(g1[n], gr[n]) < max(1.25 * rel(g0[n], gr[n]), 2e-2), (n, rel(g1[n], gr[n]), rel(g0[n], gr[n]))
 
 
@@ -133,6 +139,12 @@ def test_stem_without_cat_matches_the_cat_path(hip_lib, monkeypatch):
     rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
     assert rel(gx1, gxr) < max(1.25 * rel(gx0, gxr), 1e-2), (rel(gx1, gxr), rel(gx0, gxr))
     for n in g0:
+        if rel(g0[n], gr[n]) > 0.5:
+            # the weights of the test loss sum to zero, so the true LAB bias gradient (the sum of ALL gradient elements) is ~0
+            # and both bf16 runs hold only cancellation noise there, whose size also depends on the atomics' order: same
+            # magnitude is all that can be asked
+            assert float((g1[n].float() - gr[n].float()).norm()) < 4 * float((g0[n].float() - gr[n].float()).norm()), n
+            continue
         assert rel(g1[n], gr[n]) < max(1.25 * rel(g0[n], gr[n]), 2e-2), (n, rel(g1[n], gr[n]), rel(g0[n], gr[n]))
 
 

@@ -217,3 +217,43 @@ def test_packed_bf16_value_gradient_matches_the_float_one(hip_lib, c, shapes, np
     v32 = value.float()
     assert hip_lib.dfine_msda_bwd(_lib.ptr(v32), 0, _lib.ptr(loc), _lib.ptr(attn), _lib.ptr(go.float()), _lib.ptr(g16), 1, _lib.ptr(gl1),
                                   _lib.ptr(ga1), B, S, Lq, nH, c, len(npts), hw, np_, None) == -2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_prepare_matches_the_op_by_op_form(dtype):
+    """Locations and softmaxed weights from the two projections (dfine_decoder.py:148-166), forward and backward, against
+    the same arithmetic spelled with ATen ops on the same inputs. fp32 intermediate math both ways: 1e-6 on fp32 inputs;
+    bf16 inputs differ only in the final rounding of the two input gradients (one bf16 ulp)."""
+    from dfine_seg_amd import ops
+
+    torch.manual_seed(3)
+    dev = "cuda"
+    B, Lq, nH, pts = 3, 77, 8, [3, 6, 3]
+    P = sum(pts)
+    scale = torch.tensor([1.0 / n for n in pts for _ in range(n)], device=dev)
+    off = torch.randn(B, Lq, nH * P * 2, device=dev).to(dtype)
+    lg = (2 * torch.randn(B, Lq, nH * P, device=dev)).to(dtype)
+    ref = torch.rand(B, Lq, 4, device=dev) * 0.5 + 0.1
+    g_loc = torch.randn(B, Lq, nH, P, 2, device=dev)
+    g_w = torch.randn(B, Lq, nH, P, device=dev)
+
+    def run(fused):
+        o, l = off.clone().requires_grad_(True), lg.clone().requires_grad_(True)
+        if fused:
+            loc, w = ops.msda_prepare(o, l, ref, scale, nH)
+        else:
+            of = o.float().view(B, Lq, nH, P, 2)
+            w = torch.softmax(l.float().view(B, Lq, nH, P), dim=-1)
+            r = ref[:, :, None, None, :]
+            loc = r[..., :2] + of * (scale.view(P, 1) * 0.5) * r[..., 2:]
+        ((loc * g_loc).sum() + (w * g_w).sum()).backward()
+        return loc.detach(), w.detach(), o.grad, l.grad
+
+    a, b = run(True), run(False)
+    assert a[0].dtype == torch.float32 and a[1].dtype == torch.float32 and a[2].dtype == dtype and a[3].dtype == dtype
+    torch.testing.assert_close(a[0], b[0], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(a[1], b[1], rtol=1e-5, atol=1e-7)
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-3)
+    torch.testing.assert_close(a[2].float(), b[2].float(), **tol)
+    torch.testing.assert_close(a[3].float(), b[3].float(), **tol)
