@@ -417,46 +417,120 @@ static int launch_bwd(const void* value, const float* loc, const float* attn,
 //     loc[p]  = ref.xy + off[p] * (scale[p] * 0.5) * ref.wh          w[p] = softmax_p(logit[p])
 //     d off[p] = d loc[p] * (scale[p] * 0.5) * ref.wh                d logit[p] = w[p] * (d w[p] - sum_q w[q] d w[q])
 // (the reference boxes are detached in the decoder, dfine_decoder.py:476: no gradient flows into them)
-template <typename T>
+// P > 0: the point count is a compile-time multiple of 4 and a thread's rows (48 / 24 bytes of bf16 in, 96 / 48 bytes of fp32
+// out for P = 12) move as 8- and 16-byte accesses from registers; P == 0: any point count (n_points), element by element.
+template <typename T, int P>
 __global__ __launch_bounds__(256) void msda_prepare_fwd_kernel(const T* __restrict__ off, const T* __restrict__ logit,
                                                               const float* __restrict__ ref, const float* __restrict__ scale,
-                                                              float* __restrict__ loc, float* __restrict__ w, long long n_tok, int nH, int P) {
+                                                              float* __restrict__ loc, float* __restrict__ w, long long n_tok, int nH, int n_points) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (token, head)
   if (t >= n_tok * nH) return;
   const long long tok = t / nH;
   const float4 r = *reinterpret_cast<const float4*>(ref + tok * 4);
-  const T* o = off + t * P * 2;
-  const T* lg = logit + t * P;
-  float m = -INFINITY;
-  for (int p = 0; p < P; ++p) m = fmaxf(m, VecTraits<T>::load1(lg + p));
-  float sum = 0.f;
-  for (int p = 0; p < P; ++p) sum += __expf(VecTraits<T>::load1(lg + p) - m);
-  const float inv = 1.f / sum;
-  for (int p = 0; p < P; ++p) {
-    const float k = scale[p] * 0.5f;
-    loc[(t * P + p) * 2 + 0] = r.x + VecTraits<T>::load1(o + 2 * p) * k * r.z;
-    loc[(t * P + p) * 2 + 1] = r.y + VecTraits<T>::load1(o + 2 * p + 1) * k * r.w;
-    w[t * P + p] = __expf(VecTraits<T>::load1(lg + p) - m) * inv;
+  if constexpr (P > 0) {
+    float o[2 * P], lg[P];
+#pragma unroll
+    for (int i = 0; i < 2 * P; i += 4) load_vec<T, 4>(off + t * 2 * P + i, o + i);
+#pragma unroll
+    for (int i = 0; i < P; i += 4) load_vec<T, 4>(logit + t * P + i, lg + i);
+    float m = lg[0];
+#pragma unroll
+    for (int p = 1; p < P; ++p) m = fmaxf(m, lg[p]);
+    float sum = 0.f;
+#pragma unroll
+    for (int p = 0; p < P; ++p) lg[p] = __expf(lg[p] - m), sum += lg[p];
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float k = scale[p] * 0.5f;
+      o[2 * p] = r.x + o[2 * p] * k * r.z;
+      o[2 * p + 1] = r.y + o[2 * p + 1] * k * r.w;
+      lg[p] *= inv;
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * P; i += 4) store_vec<float, 4>(loc + t * 2 * P + i, o + i);
+#pragma unroll
+    for (int i = 0; i < P; i += 4) store_vec<float, 4>(w + t * P + i, lg + i);
+  } else {
+    const int np = n_points;
+    const T* o = off + t * np * 2;
+    const T* lg = logit + t * np;
+    float m = -INFINITY;
+    for (int p = 0; p < np; ++p) m = fmaxf(m, VecTraits<T>::load1(lg + p));
+    float sum = 0.f;
+    for (int p = 0; p < np; ++p) sum += __expf(VecTraits<T>::load1(lg + p) - m);
+    const float inv = 1.f / sum;
+    for (int p = 0; p < np; ++p) {
+      const float k = scale[p] * 0.5f;
+      loc[(t * np + p) * 2 + 0] = r.x + VecTraits<T>::load1(o + 2 * p) * k * r.z;
+      loc[(t * np + p) * 2 + 1] = r.y + VecTraits<T>::load1(o + 2 * p + 1) * k * r.w;
+      w[t * np + p] = __expf(VecTraits<T>::load1(lg + p) - m) * inv;
+    }
   }
 }
 
-template <typename T>
+template <typename T, int P>
 __global__ __launch_bounds__(256) void msda_prepare_bwd_kernel(const float* __restrict__ g_loc, const float* __restrict__ g_w,
                                                               const float* __restrict__ w, const float* __restrict__ ref,
                                                               const float* __restrict__ scale, T* __restrict__ d_off,
-                                                              T* __restrict__ d_logit, long long n_tok, int nH, int P) {
+                                                              T* __restrict__ d_logit, long long n_tok, int nH, int n_points) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_tok * nH) return;
   const long long tok = t / nH;
   const float4 r = *reinterpret_cast<const float4*>(ref + tok * 4);
-  float dot = 0.f;
-  for (int p = 0; p < P; ++p) dot += w[t * P + p] * g_w[t * P + p];
-  for (int p = 0; p < P; ++p) {
-    const float k = scale[p] * 0.5f;
-    store1(d_off + (t * P + p) * 2 + 0, g_loc[(t * P + p) * 2 + 0] * k * r.z);
-    store1(d_off + (t * P + p) * 2 + 1, g_loc[(t * P + p) * 2 + 1] * k * r.w);
-    store1(d_logit + t * P + p, w[t * P + p] * (g_w[t * P + p] - dot));
+  if constexpr (P > 0) {
+    float gl[2 * P], gw[P], ww[P];
+#pragma unroll
+    for (int i = 0; i < 2 * P; i += 4) load_vec<float, 4>(g_loc + t * 2 * P + i, gl + i);
+#pragma unroll
+    for (int i = 0; i < P; i += 4) load_vec<float, 4>(g_w + t * P + i, gw + i), load_vec<float, 4>(w + t * P + i, ww + i);
+    float dot = 0.f;
+#pragma unroll
+    for (int p = 0; p < P; ++p) dot += ww[p] * gw[p];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float k = scale[p] * 0.5f;
+      gl[2 * p] *= k * r.z;
+      gl[2 * p + 1] *= k * r.w;
+      gw[p] = ww[p] * (gw[p] - dot);
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * P; i += 4) store_vec<T, 4>(d_off + t * 2 * P + i, gl + i);
+#pragma unroll
+    for (int i = 0; i < P; i += 4) store_vec<T, 4>(d_logit + t * P + i, gw + i);
+  } else {
+    const int np = n_points;
+    float dot = 0.f;
+    for (int p = 0; p < np; ++p) dot += w[t * np + p] * g_w[t * np + p];
+    for (int p = 0; p < np; ++p) {
+      const float k = scale[p] * 0.5f;
+      store1(d_off + (t * np + p) * 2 + 0, g_loc[(t * np + p) * 2 + 0] * k * r.z);
+      store1(d_off + (t * np + p) * 2 + 1, g_loc[(t * np + p) * 2 + 1] * k * r.w);
+      store1(d_logit + t * np + p, w[t * np + p] * (g_w[t * np + p] - dot));
+    }
   }
+}
+
+template <typename T>
+static void launch_prepare_fwd(unsigned blocks, hipStream_t st, const void* off, const void* logit, const float* ref, const float* scale,
+                               float* loc, float* w, long long n_tok, int nH, int P) {
+#define DFINE_PREP_FWD(PP) hipLaunchKernelGGL((msda_prepare_fwd_kernel<T, PP>), dim3(blocks), dim3(256), 0, st, (const T*)off, (const T*)logit, ref, scale, loc, w, n_tok, nH, P)
+  if (P == 12) DFINE_PREP_FWD(12);
+  else if (P == 8) DFINE_PREP_FWD(8);
+  else if (P == 16) DFINE_PREP_FWD(16);
+  else DFINE_PREP_FWD(0);
+#undef DFINE_PREP_FWD
+}
+
+template <typename T>
+static void launch_prepare_bwd(unsigned blocks, hipStream_t st, const float* g_loc, const float* g_w, const float* w, const float* ref,
+                               const float* scale, void* d_off, void* d_logit, long long n_tok, int nH, int P) {
+#define DFINE_PREP_BWD(PP) hipLaunchKernelGGL((msda_prepare_bwd_kernel<T, PP>), dim3(blocks), dim3(256), 0, st, g_loc, g_w, w, ref, scale, (T*)d_off, (T*)d_logit, n_tok, nH, P)
+  if (P == 12) DFINE_PREP_BWD(12);
+  else if (P == 8) DFINE_PREP_BWD(8);
+  else if (P == 16) DFINE_PREP_BWD(16);
+  else DFINE_PREP_BWD(0);
+#undef DFINE_PREP_BWD
 }
 
 }  // namespace dfine
@@ -471,11 +545,9 @@ extern "C" int dfine_msda_prepare_fwd(const void* offsets, const void* logits, i
   if (blocks > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DFINE_DT_BF16)
-    hipLaunchKernelGGL(msda_prepare_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)offsets, (const bf16_t*)logits,
-                       ref_boxes, point_scale, loc, weights, n_tokens, nH, P);
+    launch_prepare_fwd<bf16_t>((unsigned)blocks, st, offsets, logits, ref_boxes, point_scale, loc, weights, n_tokens, nH, P);
   else if (dtype == DFINE_DT_F32)
-    hipLaunchKernelGGL(msda_prepare_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)offsets, (const float*)logits,
-                       ref_boxes, point_scale, loc, weights, n_tokens, nH, P);
+    launch_prepare_fwd<float>((unsigned)blocks, st, offsets, logits, ref_boxes, point_scale, loc, weights, n_tokens, nH, P);
   else
     return DFINE_E_UNSUPPORTED;
   DFINE_LAUNCH_CHECK();
@@ -491,11 +563,9 @@ extern "C" int dfine_msda_prepare_bwd(const float* grad_loc, const float* grad_w
   if (blocks > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == DFINE_DT_BF16)
-    hipLaunchKernelGGL(msda_prepare_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, grad_loc, grad_weights, weights, ref_boxes,
-                       point_scale, (bf16_t*)d_offsets, (bf16_t*)d_logits, n_tokens, nH, P);
+    launch_prepare_bwd<bf16_t>((unsigned)blocks, st, grad_loc, grad_weights, weights, ref_boxes, point_scale, d_offsets, d_logits, n_tokens, nH, P);
   else if (dtype == DFINE_DT_F32)
-    hipLaunchKernelGGL(msda_prepare_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, grad_loc, grad_weights, weights, ref_boxes,
-                       point_scale, (float*)d_offsets, (float*)d_logits, n_tokens, nH, P);
+    launch_prepare_bwd<float>((unsigned)blocks, st, grad_loc, grad_weights, weights, ref_boxes, point_scale, d_offsets, d_logits, n_tokens, nH, P);
   else
     return DFINE_E_UNSUPPORTED;
   DFINE_LAUNCH_CHECK();

@@ -220,8 +220,9 @@ def test_packed_bf16_value_gradient_matches_the_float_one(hip_lib, c, shapes, np
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pts", [[3, 6, 3], [2, 3]])  # 12 points: the register path; 5: the element-by-element one
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_prepare_matches_the_op_by_op_form(dtype):
+def test_prepare_matches_the_op_by_op_form(dtype, pts):
     """Locations and softmaxed weights from the two projections (dfine_decoder.py:148-166), forward and backward, against
     the same arithmetic spelled with ATen ops on the same inputs. fp32 intermediate math both ways: 1e-6 on fp32 inputs;
     bf16 inputs differ only in the final rounding of the two input gradients (one bf16 ulp)."""
@@ -229,7 +230,7 @@ def test_prepare_matches_the_op_by_op_form(dtype):
 
     torch.manual_seed(3)
     dev = "cuda"
-    B, Lq, nH, pts = 3, 77, 8, [3, 6, 3]
+    B, Lq, nH = 3, 77, 8
     P = sum(pts)
     scale = torch.tensor([1.0 / n for n in pts for _ in range(n)], device=dev)
     off = torch.randn(B, Lq, nH * P * 2, device=dev).to(dtype)
