@@ -6,6 +6,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from .configs import ModelSpec
 from .layers import ConvNorm, conv_pair, LayerNorm, Linear, PackedSelfAttention
 
@@ -63,6 +65,9 @@ class CSP(nn.Module):
         return self.bottlenecks(self.conv1._norm_tail(ya, ws_a, hs_a)) + self.conv2._norm_tail(yb, ws_b, hs_b)
 
 
+ELAN_BUFFER = os.environ.get("DFINE_ELAN_BUFFER", "1") != "0"  # measurement switch
+
+
 class RepNCSPELAN4(nn.Module):
     def __init__(self, c_in, c_out, c_mid, c_branch, n):
         super().__init__()
@@ -72,6 +77,20 @@ class RepNCSPELAN4(nn.Module):
         self.cv4 = ConvNorm(c_mid + 2 * c_branch, c_out, 1, act="silu")
 
     def forward(self, x):
+        from . import ops
+
+        c_mid, c_branch = self.cv1.out_channels, self.cv2[1].out_channels
+        if ELAN_BUFFER and ops.concat_buffer_supported(x, [c_mid // 2, c_mid // 2, c_branch, c_branch]):
+            # no torch.cat, no chunk: cv1 and the two branches' last norms write their channel slices of one buffer, the first
+            # branch reads the second half of cv1's slice in place, and every producer picks its slice of cv4's input
+            # gradient up from the buffer (ops.ConcatBuffer)
+            B, _, H, W = x.shape
+            buf = ops.ConcatBuffer(B, H, W, c_mid + 2 * c_branch, torch.bfloat16, x.device)
+            y = self.cv1(x, into=buf)
+            b = ops.concat_slot_slice(y, buf, c_mid // 2, c_mid // 2)
+            c = self.cv2[1](self.cv2[0](b), into=buf)
+            d = self.cv3[1](self.cv3[0](c), into=buf)
+            return self.cv4(ops.concat_read(buf, [y, c, d]))
         y = self.cv1(x)
         a, b = y.chunk(2, dim=1)
         c = self.cv2(b)

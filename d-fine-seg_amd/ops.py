@@ -498,6 +498,33 @@ class _ConcatRead(torch.autograd.Function):
         return (None,) * (1 + len(ctx.needs_input_grad) - 1)
 
 
+class _ConcatSlotSlice(torch.autograd.Function):
+    """Channels [c0, c0 + C) of a slice a producer wrote into ``buffer`` (``y``, an autograd-visible view of it), for a second
+    consumer that reads only PART of it (RepNCSPELAN4's chunk(2), hybrid_encoder.py:229-231). Backward adds that consumer's
+    gradient into the parked concat gradient in place (one strided add over C channels) and hands nothing back through
+    autograd: the producer finds the sum in its slice of ``buffer.grad`` -- no zero-padded gradient of the full slice, no
+    accumulation add over it."""
+
+    @staticmethod
+    def forward(ctx, y, buffer, c0, C):
+        ctx.slot = (buffer, c0, C)
+        return buffer.buf[..., c0 : c0 + C].permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        buffer, c0, C = ctx.slot
+        if g is not None:
+            if buffer.grad is None:
+                raise _lib.DfineHipError("concat_slot_slice: the buffer's reader has not run its backward yet")
+            buffer.grad[..., c0 : c0 + C].add_(g.permute(0, 2, 3, 1))
+        return None, None, None, None
+
+
+def concat_slot_slice(y, buffer, c0, C):
+    """``buffer`` channels [c0, c0 + C) as an NCHW-shaped view, tied to their producer's output ``y``; see _ConcatSlotSlice."""
+    return _ConcatSlotSlice.apply(y, buffer, c0, C)
+
+
 def concat_copy_in(x, buffer):
     """Copy ``x`` [B, C, H, W] into the next free channel slice of ``buffer``; returns the slice (an NCHW-shaped view)."""
     return _ConcatCopyIn.apply(x, buffer, buffer.take(x.shape[1]))

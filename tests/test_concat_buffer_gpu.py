@@ -185,3 +185,25 @@ def test_encoder_fpn_pan_without_cat_matches_the_cat_path(hip_lib, monkeypatch):
         assert rel(a, r) < max(1.25 * rel(b, r), 2e-2), (rel(a, r), rel(b, r))
     worse = [n for n in g0 if rel(g1[n], gr[n]) > max(1.25 * rel(g0[n], gr[n]), 5e-2)]
     assert len(worse) <= len(g0) // 50, worse  # a handful of near-zero-gradient parameters are pure round-off in every run
+
+
+def test_elan_block_without_cat_or_chunk_matches_the_cat_path(hip_lib, monkeypatch):
+    """RepNCSPELAN4 (hybrid_encoder.py:213-239): cv1 and the two branches' last norms write their slices of one buffer, the first
+    branch reads the second half of cv1's slice in place and adds its input gradient to the parked concat gradient
+    (ops.concat_slot_slice). Forward bit-equal to chunk + torch.cat; gradients no worse than that path against the fp32 run."""
+    from dfine_seg_amd.encoder import RepNCSPELAN4
+
+    torch.manual_seed(0)
+    block = RepNCSPELAN4(128, 64, 64, 32, 2).cuda().to(memory_format=torch.channels_last).train()
+    x = torch.randn(3, 128, 20, 28, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    cat_block, fp32_block = copy.deepcopy(block), copy.deepcopy(block)
+    y0, gx0, g0 = _run_block(cat_block, x, "cat", monkeypatch)
+    y1, gx1, g1 = _run_block(block, x, "buffer", monkeypatch)
+    _, gxr, gr = _run_block(fp32_block, x, "fp32", monkeypatch)
+    assert torch.equal(y0, y1)
+    for (n, b0), (_, b1) in zip(cat_block.named_buffers(), block.named_buffers()):
+        assert torch.equal(b0, b1), n
+    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+    assert rel(gx1, gxr) < max(1.25 * rel(gx0, gxr), 1e-2), (rel(gx1, gxr), rel(gx0, gxr))
+    worse = [n for n in g0 if rel(g1[n], gr[n]) > max(1.25 * rel(g0[n], gr[n]), 5e-2)]
+    assert len(worse) <= max(1, len(g0) // 25), [(n, rel(g1[n], gr[n]), rel(g0[n], gr[n])) for n in worse]
