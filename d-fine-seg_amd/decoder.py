@@ -124,7 +124,7 @@ class DecoderLayer(nn.Module):
         tgt = self.norm1(tgt, self.self_attn(tgt + pos, tgt, blocked))
         cross = self.cross_attn(tgt + pos, ref_boxes, value, spatial_shapes, sink, finalize).to(tgt.dtype)
         tgt = self.gateway(tgt, cross)
-        ffn = self.linear2(F.relu(self.linear1(tgt)))
+        ffn = self.linear2(ops.linear(tgt, self.linear1.weight, self.linear1.bias, relu=True))  # bias + ReLU in the GEMM epilogue
         return self.norm3(tgt, ffn, clamp=65504.0)
 
 

@@ -1439,7 +1439,8 @@ def _conv_weight_grad(weight, gyc, xc, stride, padding):
     ldy, ldx = gemm.pixel_pitch(gyc), gemm.pixel_pitch(xc)
     taps = KH * KW
     # the fp32 gradient must be laid out [K_out][KH][KW][C_in] (a channels_last weight's memory order)
-    direct = (DIRECT_WGRAD_ACCUM and weight.grad is not None and weight.grad.dtype == torch.float32
+    # (is_leaf first: the stem's zero-padded weight is a non-leaf view, and asking one for .grad warns)
+    direct = (DIRECT_WGRAD_ACCUM and weight.is_leaf and weight.grad is not None and weight.grad.dtype == torch.float32
               and _is_khwc(weight.grad))
     if direct:
         dw = weight.grad
