@@ -27,7 +27,7 @@ SIGNATURES = {
     "dfine_dwconv_bwd_data": [_c_void_p] * 3 + [_c_int] * 7 + [_c_void_p],
     "dfine_dwconv_bwd_weight": [_c_void_p] * 4 + [ctypes.c_longlong] + [_c_int] * 7 + [_c_void_p],
     "dfine_dwconv_bwd_weight_workspace": [_c_int] * 6,
-    "dfine_bn_act_fwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 9 + [_c_int] * 4 + [ctypes.c_float] * 2 + [_c_int, _c_int, _c_void_p],
+    "dfine_bn_act_fwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 9 + [_c_int] * 4 + [ctypes.c_float] * 2 + [_c_int, _c_int, _c_void_p, _c_int, _c_void_p],
     "dfine_criterion_head": [_c_void_p, _c_int] + [_c_void_p] * 17 + [_c_int] * 5 + [ctypes.c_float] * 4 + [_c_void_p, _c_void_p],
     "dfine_linear_wgrad": [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p],
     "dfine_conv_wgrad": [_c_void_p] * 3 + [_c_int] * 13 + [_c_void_p],
@@ -66,7 +66,7 @@ SIGNATURES = {
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int, _c_void_p, _c_int, _c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 _lib = None
 
 IGEMM_MAX_TAPS = 16

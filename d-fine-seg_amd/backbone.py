@@ -2,6 +2,8 @@
 src/d_fine/arch/hgnetv2.py (stem :115-166, HG_Block :189-275 with the default ``agg="se"``
 aggregation, HG_Stage :278-329); the unused ESE / padding="same" branches are not built.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -48,6 +50,10 @@ class Stem(nn.Module):
         return self.stem4(self.stem3(torch.cat([pooled, branch], 1)))
 
 
+CHAIN_BLOCKS = os.environ.get("DFINE_CHAIN_BLOCKS", "1") != "0"  # measurement switches
+FUSE_RESIDUAL = os.environ.get("DFINE_FUSE_RESIDUAL", "1") != "0"
+
+
 class LightConv(nn.Module):
     """1x1 conv+norm (no act) then depthwise kxk conv+norm+act (hgnetv2.py:83-112)."""
 
@@ -70,25 +76,39 @@ class Block(nn.Module):
         self.aggregation = nn.Sequential(ConvNorm(total, c_out // 2, 1, **kw), ConvNorm(c_out // 2, c_out, 1, **kw))
         self.residual = residual
 
-    def forward(self, x):
-        if ops.concat_buffer_supported(x, self.part_channels):
+    def make_buffer(self, B, H, W, device):
+        return ops.ConcatBuffer(B, H, W, sum(self.part_channels), torch.bfloat16, device)
+
+    def forward(self, x, buf=None, out_into=None):
+        """``buf``: this block's concat buffer when ``x`` already IS its first slice (the producer -- the previous block's
+        last norm, the stage's downsample -- wrote it there: no copy-in, and that producer's backward picks the slice of
+        the concat gradient up on load); ``out_into``: the NEXT block's buffer, whose first slice the output becomes. The
+        residual is added by the last norm kernel after its activation (ConvNorm ``post``)."""
+        if buf is not None or ops.concat_buffer_supported(x, self.part_channels):
             # no torch.cat: every layer's norm kernel writes its output into its channel slice of one buffer, the next layer
             # reads that slice in place (pixel pitch = total channels), and in backward each layer adds its slice of the
             # aggregation's input gradient on load (ops.ConcatBuffer)
-            B, _, H, W = x.shape
-            buf = ops.ConcatBuffer(B, H, W, sum(self.part_channels), torch.bfloat16, x.device)
-            parts = [ops.concat_copy_in(x, buf)]
+            if buf is None:
+                B, _, H, W = x.shape
+                buf = self.make_buffer(B, H, W, x.device)
+                parts = [ops.concat_copy_in(x, buf)]
+            else:
+                parts = [x]
             cur = x
             for layer in self.layers:
                 cur = layer(cur, into=buf)
                 parts.append(cur)
-            y = self.aggregation(ops.concat_read(buf, parts))
-        else:
-            feats = [x]
-            for layer in self.layers:
-                feats.append(layer(feats[-1]))
-            y = self.aggregation(torch.cat(feats, 1))
-        return y + x if self.residual else y
+            y = self.aggregation[0](ops.concat_read(buf, parts))
+            if FUSE_RESIDUAL or not self.residual:
+                return self.aggregation[1](y, into=out_into, post=x if self.residual else None)
+            y = self.aggregation[1](y) + x
+            return y if out_into is None else ops.concat_copy_in(y, out_into)
+        feats = [x]
+        for layer in self.layers:
+            feats.append(layer(feats[-1]))
+        y = self.aggregation(torch.cat(feats, 1))
+        y = y + x if self.residual else y
+        return y if out_into is None else ops.concat_copy_in(y, out_into)
 
 
 class Stage(nn.Module):
@@ -102,9 +122,25 @@ class Stage(nn.Module):
         ])
 
     def forward(self, x):
+        blocks = list(self.blocks)
+        chained = CHAIN_BLOCKS and all(ops.concat_buffer_supported(x, b.part_channels) for b in blocks)
+        buf = None
         if hasattr(self, "downsample"):
-            x = self.downsample(x)
-        return self.blocks(x)
+            if chained:  # the downsample's norm writes the first block's first slice
+                conv = self.downsample.conv
+                B, _, H, W = x.shape
+                out = lambda n, i: (n + 2 * conv.padding[i] - conv.kernel_size[i]) // conv.stride[i] + 1
+                buf = blocks[0].make_buffer(B, out(H, 0), out(W, 1), x.device)
+                x = self.downsample(x, into=buf)
+            else:
+                x = self.downsample(x)
+        for i, block in enumerate(blocks):
+            nxt = None
+            if chained and i + 1 < len(blocks):  # this block's last norm writes the next block's first slice
+                nxt = blocks[i + 1].make_buffer(x.shape[0], x.shape[2], x.shape[3], x.device)
+            x = block(x, buf, nxt) if chained else block(x)
+            buf = nxt
+        return x
 
 
 class HGNetv2(nn.Module):

@@ -31,6 +31,7 @@ struct NaGeom {
   int act, has_add, has_lab, training;
   float eps, momentum;
   int ldy;            // forward: pixel pitch of the OUTPUT (>= C: a channel slice of a concat buffer)
+  int ld_post;        // forward: pixel pitch of the optional residual added AFTER activation and LAB
   int ld_dy, ld_dy2;  // backward: pixel pitches of the output gradient and of its optional second part (dy + dy2)
 };
 
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 
 // Forward apply. One thread per channel of the block's slice turns the fp64 sums (training) or the
 // running statistics (eval) into scale/shift in LDS; block row 0 also keeps the books.
-template <typename T, int VEC>
+template <typename T, int VEC, bool POST>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
-    const T* __restrict__ x, const T* __restrict__ addend, T* __restrict__ y,
+    const T* __restrict__ x, const T* __restrict__ addend, const T* __restrict__ post, T* __restrict__ y,
     const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ save_mean,
     float* __restrict__ save_rstd, const float* __restrict__ lab_scale, const float* __restrict__ lab_bias, NaGeom g) {
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
   const float ls = g.has_lab ? lab_scale[0] : 1.f, lb = g.has_lab ? lab_bias[0] : 0.f;
   const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
   for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL) {
-    float v[DFINE_NA_UNROLL][VEC], a[DFINE_NA_UNROLL][VEC];
+    float v[DFINE_NA_UNROLL][VEC], a[DFINE_NA_UNROLL][VEC], r[POST ? DFINE_NA_UNROLL : 1][VEC];
     bool ok[DFINE_NA_UNROLL];
 #pragma unroll
     for (int u = 0; u < DFINE_NA_UNROLL; ++u) {
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
         const size_t off = (size_t)pix * g.C + c0;
         load_vec<T, VEC>(x + off, v[u]);
         if (g.has_add) load_vec<T, VEC>(addend + off, a[u]);
+        if (POST) load_vec<T, VEC>(post + (size_t)pix * g.ld_post + c0, r[POST ? u : 0]);
       }
     }
 #pragma unroll
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
         float z = v[u][i] * scale[i] + shift[i];
         if (g.has_add) z += a[u][i];
         v[u][i] = ls * act_fwd(z, g.act) + lb;
+        if (POST) v[u][i] += r[POST ? u : 0][i];  // the block's residual: out = lab(act(norm(x))) + residual, one rounding
       }
       store_vec<T, VEC>(y + (size_t)(first + (n + u) * blockDim.y) * g.ldy + c0, v[u]);
     }
@@ -424,7 +427,7 @@ static NaGeom make_geom(int n_pix, int C, int ppt, int act, bool has_add, bool h
   NaGeom g;
   g.n_pix = n_pix; g.C = C; g.pix_per_thread = ppt; g.act = act; g.has_add = has_add; g.has_lab = has_lab;
   g.training = training; g.eps = eps; g.momentum = momentum;
-  g.ldy = g.ld_dy = g.ld_dy2 = C;
+  g.ldy = g.ld_dy = g.ld_dy2 = g.ld_post = C;
   return g;
 }
 
@@ -432,7 +435,7 @@ template <typename T, int VEC>
 static int fwd_impl(const void* x, const void* addend, void* y, double* sums, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float* save_mean, float* save_rstd, const float* lab_scale,
                     const float* lab_bias, int n_pix, int C, int act, int training, float eps, float momentum, int phase,
-                    int ldy, hipStream_t st) {
+                    int ldy, const void* post, int ld_post, hipStream_t st) {
   NaLaunch R, A;
   if (int rc = plan<VEC>(&R, n_pix, C, reduce_target_blocks())) return rc;   // reductions: few blocks -> few contended atomics
   if (int rc = plan<VEC>(&A, n_pix, C, apply_target_blocks())) return rc;  // streaming: ~4 blocks per CU, several pixels per thread
@@ -445,8 +448,13 @@ static int fwd_impl(const void* x, const void* addend, void* y, double* sums, co
   if (phase == 1) return 0;
   NaGeom g = make_geom(n_pix, C, A.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, momentum);
   g.ldy = ldy;
-  hipLaunchKernelGGL((bn_apply_kernel<T, VEC>), A.grid, A.block, (size_t)2 * A.block.x * VEC * sizeof(float), st, (const T*)x, (const T*)addend, (T*)y, sums, gamma, beta,
-                     running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, g);
+  g.ld_post = ld_post;
+  if (post)
+    hipLaunchKernelGGL((bn_apply_kernel<T, VEC, true>), A.grid, A.block, (size_t)2 * A.block.x * VEC * sizeof(float), st, (const T*)x, (const T*)addend, (const T*)post, (T*)y, sums, gamma, beta,
+                       running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, g);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<T, VEC, false>), A.grid, A.block, (size_t)2 * A.block.x * VEC * sizeof(float), st, (const T*)x, (const T*)addend, (const T*)post, (T*)y, sums, gamma, beta,
+                       running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, g);
   DFINE_LAUNCH_CHECK();
   return 0;
 }
@@ -505,21 +513,23 @@ extern "C" int dfine_bn_act_fwd(const void* x, const void* addend, void* y, int 
                                 const float* gamma, const float* beta, float* running_mean,
                                 float* running_var, float* save_mean, float* save_rstd,
                                 const float* lab_scale, const float* lab_bias, int n_pix, int C, int act, int training, float eps,
-                                float momentum, int phase, int ldy, void* stream) {
+                                float momentum, int phase, int ldy, const void* post, int ld_post, void* stream) {
   if (!x || !y || !gamma || !beta || !running_mean || !running_var) return DFINE_E_BADARG;
   if (training && (!sums || !save_mean || !save_rstd)) return DFINE_E_BADARG;
   if (n_pix <= 0 || C <= 0 || act < 0 || act > 2 || phase < 0 || phase > 2) return DFINE_E_BADARG;
   if ((lab_scale != nullptr) != (lab_bias != nullptr)) return DFINE_E_BADARG;
   if (ldy == 0) ldy = C;
   if (ldy < C) return DFINE_E_BADARG;
+  if (ld_post == 0) ld_post = C;
+  if (post && ld_post < C) return DFINE_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const int es = dtype == DFINE_DT_BF16 ? 2 : 4;
   // a pitched output must keep the channel vectors aligned: pitch and base a multiple of the vector width
 #define FWD(T, V)                                                                                                                  \
-  ((ldy % V != 0 || (uintptr_t)y % (V * es) != 0)                                                                                  \
+  ((ldy % V != 0 || (uintptr_t)y % (V * es) != 0 || (post && (ld_post % V != 0 || (uintptr_t)post % (V * es) != 0)))                                                                                  \
        ? DFINE_E_UNSUPPORTED                                                                                                       \
        : fwd_impl<T, V>(x, addend, y, sums, gamma, beta, running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, n_pix, C, \
-                        act, training, eps, momentum, phase, ldy, st))
+                        act, training, eps, momentum, phase, ldy, post, ld_post, st))
   DFINE_NA_DISPATCH(FWD);
 #undef FWD
 }

@@ -85,30 +85,32 @@ class ConvNorm(nn.Module):
         delattr(self, "conv")
         delattr(self, self.norm_name)
 
-    def forward(self, x, addend=None, act=None, into=None):
+    def forward(self, x, addend=None, act=None, into=None, post=None):
         """``addend`` (same shape as the output) is added after the norm, before the activation;
         ``act`` overrides the constructor's activation name (used by RepVgg: silu(a + b)); ``into`` (an ops.ConcatBuffer):
-        the output becomes the buffer's next channel slice -- written there directly by the fused norm kernel."""
+        the output becomes the buffer's next channel slice -- written there directly by the fused norm kernel; ``post``
+        (same shape as the output) is added last, after activation and LAB (the HG block's residual), by the same kernel."""
         if into is not None:
             norm = getattr(self, self.norm_name, None)
             if (x.is_cuda and isinstance(norm, (nn.BatchNorm2d, FrozenBatchNorm2d))
                     and ops.batch_norm_act_supported(x.to(torch.bfloat16) if torch.is_autocast_enabled() else x, self.out_channels)):
                 # the fused norm kernel writes the slice
-                return self._forward(x, addend, act, (into, into.take(self.out_channels)))
-            return ops.concat_copy_in(self._forward(x, addend, act, None), into)  # deployed conv etc.: compute, then copy in
-        return self._forward(x, addend, act, None)
+                return self._forward(x, addend, act, (into, into.take(self.out_channels)), post)
+            return ops.concat_copy_in(self._forward(x, addend, act, None, post), into)  # deployed conv etc.: compute, then copy in
+        return self._forward(x, addend, act, None, post)
 
     @property
     def out_channels(self):
         return (self.conv_bn_fused if hasattr(self, "conv_bn_fused") else self.conv).out_channels
 
-    def _forward(self, x, addend, act, slot):
+    def _forward(self, x, addend, act, slot, post=None):
         """``slot`` = (buffer, first channel): only the fused-norm path can honour it; any other path returns None then."""
         if hasattr(self, "conv_bn_fused"):  # deployed: conv + bias (+ activation)
             y = ops.conv_bias_act(x, self.conv_bn_fused, act if act is not None else self.act_name, addend)
-            return self.lab(y) if hasattr(self, "lab") else y
+            y = self.lab(y) if hasattr(self, "lab") else y
+            return y if post is None else y + post
         y, ws, have_stats = self._conv(x)
-        return self._norm_tail(y, ws, have_stats, addend, act, slot)
+        return self._norm_tail(y, ws, have_stats, addend, act, slot, post)
 
     def _pairable(self, x):
         """This layer's conv can be one half of ops.dense_conv_pair: plain dense stride-1 conv on the bf16 GPU path."""
@@ -150,7 +152,7 @@ class ConvNorm(nn.Module):
             x = conv(x)
         return x, ws, have_stats
 
-    def _norm_tail(self, x, ws, have_stats, addend=None, act=None, slot=None):
+    def _norm_tail(self, x, ws, have_stats, addend=None, act=None, slot=None, post=None):
         """norm (+ addend) + activation (+ LAB) of a conv output."""
         conv = self.conv
         norm = getattr(self, self.norm_name)
@@ -166,7 +168,7 @@ class ConvNorm(nn.Module):
                 x, norm.weight, norm.bias, norm.running_mean, norm.running_var, act_name,
                 lab.scale if lab is not None else None, lab.bias if lab is not None else None, addend,
                 training=batch_stats, momentum=getattr(norm, "momentum", 0.1) or 0.1, eps=norm.eps, ws=ws, have_stats=have_stats,
-                slot=slot)
+                slot=slot, post=post)
         if slot is not None:
             raise ops._lib.DfineHipError("ConvNorm: a concat slot needs the fused norm kernel")
         x = norm(x)
@@ -176,7 +178,7 @@ class ConvNorm(nn.Module):
             x = _ACTS[act_name](x)
         if lab is not None:
             x = lab(x)
-        return x
+        return x if post is None else x + post
 
     def _flush_batch_counter(self, *args):
         # nn.BatchNorm2d counts forward calls in ``num_batches_tracked``; the fused path counts on the

@@ -550,12 +550,14 @@ class _BatchNormAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, addend, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, eps, momentum, training,
-                ws=None, have_stats=False, slot=None):
+                ws=None, have_stats=False, slot=None, post=None):
         _lib.require_gpu(x, gamma, beta)
         lib = _lib.load()
         B, C, H, W = x.shape
         xl = _nhwc(x)
         al = _nhwc(addend.to(x.dtype)) if addend is not None else None
+        pl, ld_post = (None, 0) if post is None else _grad_rows(post.to(x.dtype).permute(0, 2, 3, 1), C)  # pixel rows, any pitch
+        ctx.has_post = post is not None
         n_pix = B * H * W
         ldy = 0
         if slot is not None:  # write the output as a channel slice of a concat buffer (see ConcatBuffer)
@@ -582,9 +584,10 @@ class _BatchNormAct(torch.autograd.Function):
         rc = 0
         if training and not have_stats:
             with _lib.timed("bn_stats", xl.numel() * es, f"{n_pix}x{C}"):
-                rc = lib.dfine_bn_act_fwd(*args, 1, ldy, _lib.stream_ptr())
-        with _lib.timed("bn_apply", (xl.numel() + y.numel() + (al.numel() if al is not None else 0)) * es, f"{n_pix}x{C}"):
-            rc = rc or lib.dfine_bn_act_fwd(*args, 2, ldy, _lib.stream_ptr())
+                rc = lib.dfine_bn_act_fwd(*args, 1, ldy, None, 0, _lib.stream_ptr())
+        with _lib.timed("bn_apply", (xl.numel() + y.numel() + (al.numel() if al is not None else 0) + (xl.numel() if pl is not None else 0)) * es,
+                        f"{n_pix}x{C}"):
+            rc = rc or lib.dfine_bn_act_fwd(*args, 2, ldy, _lib.ptr(pl), ld_post, _lib.stream_ptr())
         _lib.check(rc, "dfine_bn_act_fwd")
         if not training:  # frozen / eval statistics: the backward kernel reads them from the same two buffers
             save_mean = running_mean.detach().float()
@@ -607,10 +610,14 @@ class _BatchNormAct(torch.autograd.Function):
             gy2, ld2 = _grad_rows(ctx.slot[0].grad[..., ctx.slot[1] : ctx.slot[1] + C].to(xl.dtype), C)
         if grad_y is None:
             if gy2 is None:
-                return (None,) * 15
+                return (None,) * 16
             gy, ld1, gy2, ld2 = gy2, ld2, None, 0
         else:
             gy, ld1 = _grad_rows(grad_y.to(xl.dtype).permute(0, 2, 3, 1), C)
+        dpost = None
+        if ctx.has_post:  # the residual's gradient is the output gradient itself (both parts of it)
+            dpost = gy if gy2 is None else gy + gy2
+            dpost = dpost.permute(0, 3, 1, 2)
         dx = torch.empty_like(xl)
         dadd = torch.empty_like(xl) if al is not None else None
         # one zeroed workspace: fp64 reductions [8 replicas][4C] (as 64C floats) | dgamma [C] | dbeta [C] | dlab [2]
@@ -641,11 +648,11 @@ class _BatchNormAct(torch.autograd.Function):
             rc = rc or lib.dfine_bn_act_bwd(*args, 2, _lib.stream_ptr())
         _lib.check(rc, "dfine_bn_act_bwd")
         if direct or not wants_param_grads:
-            return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None) + (None,) * 13
+            return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None) + (None,) * 13 + (dpost,)
         return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None,
                 dgamma.to(g_dtype), dbeta.to(g_dtype), None, None,
                 dlab[0:1].to(lab_dtype) if ls32 is not None else None,
-                dlab[1:2].to(lab_dtype) if ls32 is not None else None, None, None, None, None, None, None, None)
+                dlab[1:2].to(lab_dtype) if ls32 is not None else None, None, None, None, None, None, None, None, dpost)
 
 
 def bn_workspace(channels, device):
@@ -655,15 +662,15 @@ def bn_workspace(channels, device):
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, lab_scale=None, lab_bias=None,
-                   addend=None, training=True, momentum=0.1, eps=1e-5, ws=None, have_stats=False, slot=None):
-    """Fused ``lab_scale * act(batch_norm(x) + addend) + lab_bias`` on a channels_last map
+                   addend=None, training=True, momentum=0.1, eps=1e-5, ws=None, have_stats=False, slot=None, post=None):
+    """Fused ``lab_scale * act(batch_norm(x) + addend) + lab_bias (+ post)`` on a channels_last map
     (float32 or bfloat16). ``lab_scale`` / ``lab_bias`` are float tensors [1] (both or neither);
     ``act`` is None, "relu" or "silu". In training mode the running statistics are updated in place exactly like
     nn.BatchNorm2d (momentum, unbiased variance)."""
     if x.dtype not in (torch.float32, torch.bfloat16):
         x = x.float()
     return _BatchNormAct.apply(x, addend, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, float(eps),
-                               float(momentum), bool(training), ws, bool(have_stats), slot)
+                               float(momentum), bool(training), ws, bool(have_stats), slot, post)
 
 
 def batch_norm_act_supported(x, channels):

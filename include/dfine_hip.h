@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 15
+#define DFINE_ABI_VERSION 16
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -180,12 +180,15 @@ int dfine_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* wor
  *   optional second part `dy2` (pitch `ld_dy2`) is added on load -- a layer whose output feeds the next layer AND a concat
  *   receives (next layer's input gradient) + (a channel slice of the concat's gradient) without an add kernel or a copy.
  *   Pitches and bases must keep the channel vectors aligned (multiples of the vector width), else DFINE_E_UNSUPPORTED.
+ * `post` (NULL or [n_pix, C] of the same dtype, pitch `ld_post`): added AFTER activation and LAB, y = lab(act(z)) + post --
+ *   the residual of HG_Block.forward (hgnetv2.py:267-268, `x = x + identity`) without an add kernel. It does not enter the
+ *   backward kernels: its gradient is the output gradient itself.
  * ------------------------------------------------------------------------------------- */
 int dfine_bn_act_fwd(const void* x, const void* addend, void* y, int dtype, double* sums,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float* save_mean, float* save_rstd, const float* lab_scale, const float* lab_bias,
                      int n_pix, int C, int act, int training, float eps, float momentum, int phase,
-                     int ldy, void* stream);
+                     int ldy, const void* post, int ld_post, void* stream);
 int dfine_bn_act_bwd(const void* x, const void* addend, const void* dy, int ld_dy, const void* dy2, int ld_dy2,
                      int dtype, const float* save_mean, const float* save_rstd, const float* gamma,
                      const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
