@@ -51,6 +51,8 @@ SIGNATURES = {
     "dfine_gate_mix_bwd": [_c_void_p] * 4 + [_c_int] + [_c_void_p] * 3 + [ctypes.c_longlong, _c_int, _c_void_p],
     "dfine_msda_prepare_fwd": [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 4 + [ctypes.c_longlong, _c_int, _c_int, _c_void_p],
     "dfine_msda_prepare_bwd": [_c_void_p] * 5 + [_c_int, _c_void_p, _c_void_p, ctypes.c_longlong, _c_int, _c_int, _c_void_p],
+    "dfine_bilinear_add_fwd": [_c_void_p, _c_void_p, _c_int, _c_void_p] + [_c_int] * 6 + [_c_void_p],
+    "dfine_bilinear_bwd": [_c_void_p, _c_int, _c_void_p] + [_c_int] * 6 + [_c_void_p],
     "dfine_row_max": [_c_void_p, _c_int, _c_void_p, ctypes.c_longlong, _c_int, _c_void_p],
     "dfine_stage_images": [_c_void_p, _c_void_p] + [_c_int] * 6 + [_c_void_p] * 3,
     "dfine_postprocess_topk": [_c_void_p, _c_int] + [_c_void_p] * 6 + [_c_int] * 7 + [_c_void_p],
@@ -66,7 +68,7 @@ SIGNATURES = {
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int, _c_void_p, _c_int, _c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 _lib = None
 
 IGEMM_MAX_TAPS = 16

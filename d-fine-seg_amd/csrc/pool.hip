@@ -160,6 +160,120 @@ static int launch_upsample(bool fwd, const void* in, void* out, int B, int H, in
   return 0;
 }
 
+// Bilinear resize (align_corners = false, PyTorch's source-index rule) of a channel-last map, ADDED to a base map of the output
+// size: out = base + resize(x) -- the top-down sum of MaskPixelDecoder (dfine_decoder.py:352-360: `x = x + F.interpolate(lat,
+// size, mode="bilinear")`) in one launch; backward = each INPUT pixel gathers its weights over the output pixels that read it
+// (no atomics; the stock backward scatters with float atomics in fp32). fp32 arithmetic, one rounding.
+struct BilinearTap {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ BilinearTap bilinear_tap(int dst, float scale, int n_in) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  BilinearTap t;
+  t.i0 = (int)src;
+  if (t.i0 > n_in - 1) t.i0 = n_in - 1;
+  t.i1 = t.i0 + (t.i0 < n_in - 1 ? 1 : 0);
+  t.l1 = src - (float)t.i0;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_add_fwd_kernel(const T* __restrict__ x, const T* __restrict__ base, T* __restrict__ y, int B,
+                                                              int h, int w, int H, int W, int C, float sy, float sx) {
+  constexpr int V = VecTraits<T>::kElems;
+  const int cpp = C / V;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)B * H * W * cpp) return;
+  const int c0 = (int)(t % cpp) * V;
+  size_t p = t / cpp;
+  const int X = (int)(p % W);
+  p /= W;
+  const int Y = (int)(p % H), b = (int)(p / H);
+  const BilinearTap ty = bilinear_tap(Y, sy, h), tx = bilinear_tap(X, sx, w);
+  const T* xb = x + (size_t)b * h * w * C + c0;
+  float v00[V], v01[V], v10[V], v11[V], o[V];
+  load_vec<T, V>(xb + ((size_t)ty.i0 * w + tx.i0) * C, v00);
+  load_vec<T, V>(xb + ((size_t)ty.i0 * w + tx.i1) * C, v01);
+  load_vec<T, V>(xb + ((size_t)ty.i1 * w + tx.i0) * C, v10);
+  load_vec<T, V>(xb + ((size_t)ty.i1 * w + tx.i1) * C, v11);
+  const size_t off = (((size_t)b * H + Y) * W + X) * C + c0;
+  if (base) load_vec<T, V>(base + off, o);
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const float r = ty.l0 * (tx.l0 * v00[i] + tx.l1 * v01[i]) + ty.l1 * (tx.l0 * v10[i] + tx.l1 * v11[i]);
+    o[i] = base ? o[i] + r : r;
+  }
+  store_vec<T, V>(y + off, o);
+}
+
+constexpr int BILINEAR_MAX_CAND = 20;  // output pixels along one axis that can read one input pixel: <= 2 * (out / in) + 2
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int B, int h, int w, int H, int W,
+                                                          int C, float sy, float sx) {
+  constexpr int V = VecTraits<T>::kElems;
+  const int cpp = C / V;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)B * h * w * cpp) return;
+  const int c0 = (int)(t % cpp) * V;
+  size_t p = t / cpp;
+  const int xx = (int)(p % w);
+  p /= w;
+  const int yy = (int)(p % h), b = (int)(p / h);
+  // candidate output rows / columns and this input pixel's weight in each (0 for a candidate that does not read it)
+  auto span = [](int i, float scale, int n_out, int& lo, int& hi) {
+    const float inv = 1.f / scale;
+    lo = (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1;
+    hi = (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1;
+    if (lo < 0 || i == 0) lo = 0;
+    if (hi > n_out - 1) hi = n_out - 1;
+  };
+  int ylo, yhi, xlo, xhi;
+  span(yy, sy, H, ylo, yhi);
+  span(xx, sx, W, xlo, xhi);
+  float wx[BILINEAR_MAX_CAND];
+  const int nx = min(xhi - xlo + 1, BILINEAR_MAX_CAND);
+  for (int j = 0; j < nx; ++j) {
+    const BilinearTap tx = bilinear_tap(xlo + j, sx, w);
+    wx[j] = (tx.i0 == xx ? tx.l0 : 0.f) + (tx.i1 == xx ? tx.l1 : 0.f);
+  }
+  float acc[V], g[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) acc[i] = 0.f;
+  for (int Y = ylo; Y <= yhi; ++Y) {
+    const BilinearTap ty = bilinear_tap(Y, sy, h);
+    const float wy = (ty.i0 == yy ? ty.l0 : 0.f) + (ty.i1 == yy ? ty.l1 : 0.f);
+    if (wy == 0.f) continue;
+    const T* row = gy + (((size_t)b * H + Y) * W) * C + c0;
+    for (int j = 0; j < nx; ++j) {
+      if (wx[j] == 0.f) continue;
+      load_vec<T, V>(row + (size_t)(xlo + j) * C, g);
+      const float wgt = wy * wx[j];
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc[i] += wgt * g[i];
+    }
+  }
+  store_vec<T, V>(gx + (((size_t)b * h + yy) * w + xx) * C + c0, acc);
+}
+
+template <typename T>
+static int launch_bilinear(bool fwd, const void* in, const void* base, void* out, int B, int h, int w, int H, int W, int C, hipStream_t st) {
+  constexpr int V = VecTraits<T>::kElems;
+  if (C % V != 0) return DFINE_E_UNSUPPORTED;
+  if (H < h || W < w || 2 * ((H + h - 1) / h) + 4 > BILINEAR_MAX_CAND || 2 * ((W + w - 1) / w) + 4 > BILINEAR_MAX_CAND) return DFINE_E_UNSUPPORTED;  // up-sampling by <= 8
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const size_t items = (size_t)B * (fwd ? H : h) * (fwd ? W : w) * (C / V);
+  const size_t blocks = (items + 255) / 256;
+  if (blocks > 0x7fffffffULL) return DFINE_E_UNSUPPORTED;
+  if (fwd) hipLaunchKernelGGL(bilinear_add_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)in, (const T*)base, (T*)out, B, h, w, H, W, C, sy, sx);
+  else hipLaunchKernelGGL(bilinear_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)in, (T*)out, B, h, w, H, W, C, sy, sx);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T>
 static int launch_pool(bool fwd, const void* x, const void* gy, void* out, int B, int H, int W, int C, int ld, hipStream_t st) {
   constexpr int V = VecTraits<T>::kElems;
@@ -210,5 +324,22 @@ extern "C" int dfine_upsample2x_bwd(const void* gy, int ld_gy, int dtype, void* 
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return DFINE_E_BADARG;
   if (dtype == DFINE_DT_F32) return launch_upsample<float>(false, gy, gx, B, H, W, C, ld_gy, (hipStream_t)stream);
   if (dtype == DFINE_DT_BF16) return launch_upsample<bf16_t>(false, gy, gx, B, H, W, C, ld_gy, (hipStream_t)stream);
+  return DFINE_E_UNSUPPORTED;
+}
+
+extern "C" int dfine_bilinear_add_fwd(const void* x, const void* base, int dtype, void* y, int B, int h, int w, int H, int W, int C,
+                                      void* stream) {
+  if (!x || !y) return DFINE_E_BADARG;
+  if (B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || C <= 0) return DFINE_E_BADARG;
+  if (dtype == DFINE_DT_F32) return launch_bilinear<float>(true, x, base, y, B, h, w, H, W, C, (hipStream_t)stream);
+  if (dtype == DFINE_DT_BF16) return launch_bilinear<bf16_t>(true, x, base, y, B, h, w, H, W, C, (hipStream_t)stream);
+  return DFINE_E_UNSUPPORTED;
+}
+
+extern "C" int dfine_bilinear_bwd(const void* gy, int dtype, void* gx, int B, int h, int w, int H, int W, int C, void* stream) {
+  if (!gy || !gx) return DFINE_E_BADARG;
+  if (B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || C <= 0) return DFINE_E_BADARG;
+  if (dtype == DFINE_DT_F32) return launch_bilinear<float>(false, gy, nullptr, gx, B, h, w, H, W, C, (hipStream_t)stream);
+  if (dtype == DFINE_DT_BF16) return launch_bilinear<bf16_t>(false, gy, nullptr, gx, B, h, w, H, W, C, (hipStream_t)stream);
   return DFINE_E_UNSUPPORTED;
 }

@@ -195,7 +195,7 @@ class MaskPixelDecoder(nn.Module):
         x = self._conv_bn(self.lateral[0], self.bn[0], feats[0])
         size = x.shape[-2:]
         for i in range(1, len(feats)):
-            x = x + F.interpolate(self._conv_bn(self.lateral[i], self.bn[i], feats[i]), size=size, mode="bilinear", align_corners=False)
+            x = ops.bilinear_add(x, self._conv_bn(self.lateral[i], self.bn[i], feats[i]))  # x + F.interpolate(..., size, "bilinear")
         x = self._conv_bn(self.enc_proj, self.enc_bn, enc_s8, addend=x)  # same size: the reference's bilinear resize is the identity
         return self._conv_bn(self.upconv, self.bn1, x, act="relu", transposed=True)
 

@@ -806,6 +806,46 @@ def stem_pool(x, into=None):
     return _StemPool.apply(x, (into, into.take(x.shape[1])) if into is not None else None)
 
 
+class _BilinearAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, base, x):
+        _lib.require_gpu(x)
+        lib = _lib.load()
+        xl, bl = _nhwc(x), _nhwc(base)
+        B, h, w, C = xl.shape
+        _, H, W, _ = bl.shape
+        y = torch.empty_like(bl)
+        with _lib.timed("bilinear_add_fwd", (xl.numel() + 2 * bl.numel()) * xl.element_size()):
+            rc = lib.dfine_bilinear_add_fwd(_lib.ptr(xl), _lib.ptr(bl), _lib.dtype_code(xl), _lib.ptr(y), B, h, w, H, W, C, _lib.stream_ptr())
+        _lib.check(rc, "dfine_bilinear_add_fwd")
+        ctx.meta = (B, h, w, H, W, C)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, h, w, H, W, C = ctx.meta
+        lib = _lib.load()
+        gyl = _nhwc(gy)
+        gx = torch.empty(B, h, w, C, dtype=gyl.dtype, device=gyl.device)
+        with _lib.timed("bilinear_bwd", (gx.numel() + gyl.numel()) * gx.element_size()):
+            rc = lib.dfine_bilinear_bwd(_lib.ptr(gyl), _lib.dtype_code(gyl), _lib.ptr(gx), B, h, w, H, W, C, _lib.stream_ptr())
+        _lib.check(rc, "dfine_bilinear_bwd")
+        return gy, gx.permute(0, 3, 1, 2)
+
+
+def bilinear_add(base, x):
+    """``base + F.interpolate(x, size=base.shape[-2:], mode="bilinear", align_corners=False)`` (MaskPixelDecoder's top-down
+    sum, dfine_decoder.py:352-360). One HIP launch forward, one gather launch backward for channels_last bf16 / fp32 maps on the
+    GPU that are up-sampled by at most 8; ATen otherwise."""
+    C = x.shape[1]
+    ok = (x.is_cuda and x.dtype == base.dtype and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 4
+          and base.shape[:2] == x.shape[:2] and C % (16 // x.element_size()) == 0
+          and all(o >= i and -(-o // i) <= 8 for o, i in zip(base.shape[-2:], x.shape[-2:])))
+    if not ok:
+        return base + torch.nn.functional.interpolate(x, size=base.shape[-2:], mode="bilinear", align_corners=False)
+    return _BilinearAdd.apply(base, x)
+
+
 class _Upsample2x(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, slot):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 16
+#define DFINE_ABI_VERSION 17
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -349,6 +349,17 @@ int dfine_stem_pool_bwd(const void* x, const void* gy, int ld_gy, int dtype, voi
  * ------------------------------------------------------------------------------------- */
 int dfine_upsample2x_fwd(const void* x, int dtype, void* y, int B, int H, int W, int C, int ldy, void* stream);
 int dfine_upsample2x_bwd(const void* gy, int ld_gy, int dtype, void* gx, int B, int H, int W, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * out = base + bilinear_resize(x) (align_corners = false, F.interpolate's source-index rule), channel-last maps: the top-down
+ * sum of MaskPixelDecoder.forward (src/d_fine/arch/dfine_decoder.py:352-360, `x = x + F.interpolate(lat, size=..., mode="bilinear")`)
+ * in one launch, and the resize's backward as a gather (every input pixel sums its weights over the output pixels that read it:
+ * no atomics, bitwise reproducible). x [B, h, w, C], base (may be NULL) / y / gy [B, H, W, C], gx [B, h, w, C], bf16 or f32, dense;
+ * H >= h, W >= w, ratios <= 8; C a multiple of the 16-byte channel vector. The base's gradient is gy itself.
+ * ------------------------------------------------------------------------------------- */
+int dfine_bilinear_add_fwd(const void* x, const void* base, int dtype, void* y, int B, int h, int w, int H, int W, int C,
+                           void* stream);
+int dfine_bilinear_bwd(const void* gy, int dtype, void* gx, int B, int h, int w, int H, int W, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Mask loss of the matched queries (reference src/d_fine/dfine_criterion.py:272-357: _focal_loss_mask,

@@ -120,7 +120,7 @@ class _StockOps:
 
         names = ("batch_norm_act_supported", "dense_conv", "depthwise_conv2d", "stem_pool_supported", "add_layer_norm_supported",
                  "linear", "self_attention_supported", "embedding", "conv_transpose2x2", "concat_buffer_supported",
-                 "dense_conv_pair")
+                 "dense_conv_pair", "bilinear_add")
         self.ops, self.saved = ops, {n: getattr(ops, n) for n in names}
         ops.batch_norm_act_supported = lambda x, c: False
         ops.concat_buffer_supported = lambda x, parts: False  # torch.cat
@@ -135,6 +135,7 @@ class _StockOps:
         ops.self_attention_supported = lambda qk, v, h: False
         ops.embedding = lambda idx, w, padding_idx=None: F.embedding(idx, w, padding_idx)
         ops.conv_transpose2x2 = lambda x, w, stats=None: F.conv_transpose2d(x, w, None, 2)
+        ops.bilinear_add = lambda base, x: base + F.interpolate(x, size=base.shape[-2:], mode="bilinear", align_corners=False)
         return self
 
     def __exit__(self, *exc):

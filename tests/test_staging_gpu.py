@@ -93,3 +93,36 @@ def test_mask_targets_through_a_multiscale_resize(hip_lib):
         mid = (torch.nn.functional.interpolate(m.unsqueeze(1).float(), size=(Hv, Wv), mode="nearest").squeeze(1) > 0.5).to(torch.uint8)
         ref = torch.nn.functional.interpolate(mid.unsqueeze(1).float(), size=(oh, ow), mode="nearest").squeeze(1).clamp(0, 1)
         assert torch.equal(got[i, : m.shape[0]], ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [((10, 12), (20, 24)), ((5, 6), (20, 24)), ((7, 9), (20, 25)), ((20, 24), (20, 24))])
+def test_bilinear_add_matches_interpolate(dtype, shape):
+    """``base + F.interpolate(x, size, mode="bilinear", align_corners=False)`` (MaskPixelDecoder's top-down sum) forward, and
+    the resize's backward as a gather against ATen's scatter, on x2, x4, a non-integer ratio and the identity. fp32: 1e-6
+    (same arithmetic); bf16: the fused form rounds once where ATen rounds the resized map and the sum (one bf16 ulp)."""
+    import torch.nn.functional as F
+
+    from dfine_seg_amd import ops
+
+    torch.manual_seed(2)
+    (h, w), (H, W) = shape
+    B, C = 3, 32
+    x = torch.randn(B, C, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    base = torch.randn(B, C, H, W, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(B, C, H, W, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    res = []
+    for fused in (True, False):
+        xs, bs = x.clone().requires_grad_(True), base.clone().requires_grad_(True)
+        if fused:
+            y = ops.bilinear_add(bs, xs)
+        else:
+            y = bs.float() + F.interpolate(xs.float(), size=(H, W), mode="bilinear", align_corners=False)
+        y.backward(g.to(y.dtype))
+        res.append((y.detach().float(), xs.grad.float(), bs.grad.float()))
+    (y1, gx1, gb1), (y0, gx0, gb0) = res
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=8e-3, atol=2e-2)
+    torch.testing.assert_close(y1, y0, **tol)
+    torch.testing.assert_close(gx1, gx0, **tol)
+    assert torch.equal(gb1, gb0)
