@@ -10,6 +10,8 @@ never synchronises with the host:
   * ``num_boxes`` / ``num_boxes_go`` stay on the device and are all-reduced together as one
     2-float message (the reference issues two all-reduces and two ``.item()``).
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -20,6 +22,7 @@ from .configs import CriterionSpec
 from .decoder import weighting_function
 from .targets import TargetBatch
 
+BATCH_MASK_HEADS = os.environ.get("DFINE_BATCH_MASK_HEADS", "1") != "0"  # measurement switch
 _DUMMY_BOX = (0.5, 0.5, 1.0, 1.0)  # stands in for "no target" so IoU/GIoU stay finite before masking
 _dummy_cache = {}
 
@@ -163,10 +166,17 @@ class DFINECriterion(nn.Module):
             cache["mask_fg"] = cache["mask_targets"].flatten(2).mean(2)  # [B, G]
         tgt, fg = cache["mask_targets"], cache["mask_fg"]
         G = tgt.shape[1]
-        rows = embed.gather(1, q.unsqueeze(-1).expand(-1, -1, embed.shape[-1]))  # [B, M, C]
-        pred = torch.einsum("bmc,bchw->bmhw", rows.to(feat.dtype), feat)  # [B, M, Hm, Wm], M = groups * G
         alpha = 0.5 + 0.25 * (1 - 2 * fg).clamp(-1, 1)  # [B, G]
-        if self.fused and pred.is_cuda and (Hm * Wm) % 8 == 0 and B * M <= 65535:
+        batched = cache.get("mask_stats", {}).get(id(embed))  # all heads' logits formed by ONE GEMM (_batched_mask_stats)
+        if batched is None:
+            rows = embed.gather(1, q.unsqueeze(-1).expand(-1, -1, embed.shape[-1]))  # [B, M, C]
+            pred = torch.einsum("bmc,bchw->bmhw", rows.to(feat.dtype), feat)  # [B, M, Hm, Wm], M = groups * G
+        if batched is not None:
+            stats = batched  # [B, groups, G, 3]
+            focal = stats[..., 0] / float(Hm * Wm)
+            inter, psum = stats[..., 1], stats[..., 2]
+            tsum = (fg * float(Hm * Wm)).unsqueeze(1)
+        elif self.fused and pred.is_cuda and (Hm * Wm) % 8 == 0 and B * M <= 65535:
             # HIP: per-row sums of the focal terms, p*t and p in one pass (and one pass backward)
             stats = ops.mask_row_stats(pred.reshape(B, M, Hm * Wm), tgt.reshape(B, G, Hm * Wm), alpha).view(B, groups, G, 3)
             focal = stats[..., 0] / float(Hm * Wm)
@@ -186,6 +196,38 @@ class DFINECriterion(nn.Module):
         n = w.sum().clamp(min=1)  # mean over the matched pairs, like the reference's .mean() over gathered rows
         zero_if_none = (w.sum() > 0).float()
         return {"loss_mask_bce": (focal * w).sum() / n * zero_if_none, "loss_mask_dice": (dice * w).sum() / n * zero_if_none}
+
+    def _batched_mask_stats(self, jobs, tb: TargetBatch, cache):
+        """The matched rows of EVERY head against the shared feature map in one GEMM and one statistics launch: the
+        reference forms ``einsum(embed_rows, mask_feat)`` once per head (dfine_criterion.py:272-357 under every aux / dn
+        output), which reads the [B, C, H/4, W/4] feature map once per head forward and twice backward and leaves autograd
+        to add the heads' feature-map gradients one by one (8 heads at 640^2: 7 adds over a 420 MB map). Rows of all heads
+        are concatenated along M (row m still belongs to ground truth m % G), so the per-row results are the same numbers.
+        Fills cache["mask_stats"][id(embed)] = [B, groups, G, 3] per head; leaves it empty when the fused kernel does not
+        apply (the per-head path then runs)."""
+        feat = cache["mask_feat"]
+        jobs = [(out["pred_mask_embed"], pairs) for out, pairs in jobs if pairs is not None and "pred_mask_embed" in out]
+        if not (self.fused and feat is not None and feat.is_cuda and len(jobs) > 1):
+            return
+        B = feat.shape[0]
+        Hm, Wm = feat.shape[-2:]
+        total = sum(int(p[0].shape[1]) for _, p in jobs)
+        if (Hm * Wm) % 8 != 0 or B * total > 65535 or len({e.dtype for e, _ in jobs}) != 1:
+            return
+        if "mask_targets" not in cache:
+            cache["mask_targets"] = tb.dense_mask_targets(Hm, Wm, feat.device)  # [B, G, Hm, Wm] fp32
+            cache["mask_fg"] = cache["mask_targets"].flatten(2).mean(2)  # [B, G]
+        tgt, fg = cache["mask_targets"], cache["mask_fg"]
+        G = tgt.shape[1]
+        alpha = 0.5 + 0.25 * (1 - 2 * fg).clamp(-1, 1)
+        rows = torch.cat([e.gather(1, q.unsqueeze(-1).expand(-1, -1, e.shape[-1])) for e, (q, _, _) in jobs], 1)  # [B, sum M, C]
+        pred = torch.einsum("bmc,bchw->bmhw", rows.to(feat.dtype), feat)
+        stats = ops.mask_row_stats(pred.reshape(B, total, Hm * Wm), tgt.reshape(B, G, Hm * Wm), alpha).view(B, total // G, G, 3)
+        done, g0 = {}, 0
+        for e, (_, _, groups) in jobs:
+            done[id(e)] = stats[:, g0 : g0 + groups]
+            g0 += groups
+        cache["mask_stats"] = done
 
     # ------------------------------------------------------------------ forward
     @staticmethod
@@ -277,6 +319,17 @@ class DFINECriterion(nn.Module):
         else:
             head = self._dense_heads(tb, go, gt_of_query, num_boxes, num_boxes_go, cache, losses)
 
+        if with_masks:  # every head's mask logits from one GEMM (same call order as below)
+            jobs = [(main, own_pairs(0))] + [(o, own_pairs(1 + i)) for i, o in enumerate(aux)]
+            jobs += [(outputs["pre_outputs"], own_pairs(1 + len(aux)))] + [(o, own_pairs(2 + len(aux) + i)) for i, o in enumerate(enc)]
+            if has_dn:
+                jobs += [(o, dn_pairs) for o in outputs["dn_outputs"]]
+                if "dn_pred_mask_embed" in outputs:
+                    jobs.append(({"pred_mask_embed": outputs["dn_pred_mask_embed"]}, dn_pairs))
+                jobs.append((outputs["dn_pre_outputs"], dn_pairs))
+            if BATCH_MASK_HEADS:
+                self._batched_mask_stats(jobs, tb, cache)
+
         # order of the reference's loss dict: main, aux_i, pre, enc_i, dn_i, dn_final (masks), dn_pre
         head(main, "", 0, local=True)
         mask_terms(main, own_pairs(0), "")
@@ -293,7 +346,7 @@ class DFINECriterion(nn.Module):
                 head(out, f"_dn_{i}", None, local=True, dn=(dn_assign, dn_nb))
                 mask_terms(out, dn_pairs, f"_dn_{i}")
             if "dn_pred_mask_embed" in outputs and with_masks:
-                mask_terms({"pred_mask_embed": outputs["dn_pred_mask_embed"]}, dn_pairs, "_dn_final")
+                mask_terms({"pred_mask_embed": outputs["dn_pred_mask_embed"]}, dn_pairs, "_dn_final")  # same tensor as in ``jobs``: id() keyed
             head(outputs["dn_pre_outputs"], "_dn_pre", None, local=True, dn=(dn_assign, dn_nb))
             mask_terms(outputs["dn_pre_outputs"], dn_pairs, "_dn_pre")
         # the reference's per-term nan_to_num (dfine_criterion.py:576-578) as ONE launch over the stacked terms
