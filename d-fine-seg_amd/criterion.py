@@ -170,7 +170,7 @@ class DFINECriterion(nn.Module):
         batched = cache.get("mask_stats", {}).get(id(embed))  # all heads' logits formed by ONE GEMM (_batched_mask_stats)
         if batched is None:
             rows = embed.gather(1, q.unsqueeze(-1).expand(-1, -1, embed.shape[-1]))  # [B, M, C]
-            pred = torch.einsum("bmc,bchw->bmhw", rows.to(feat.dtype), feat)  # [B, M, Hm, Wm], M = groups * G
+            pred = ops.mask_logits_rows(rows, feat)  # [B, M, Hm, Wm], M = groups * G
         if batched is not None:
             stats = batched  # [B, groups, G, 3]
             focal = stats[..., 0] / float(Hm * Wm)
@@ -221,7 +221,7 @@ class DFINECriterion(nn.Module):
         G = tgt.shape[1]
         alpha = 0.5 + 0.25 * (1 - 2 * fg).clamp(-1, 1)
         rows = torch.cat([e.gather(1, q.unsqueeze(-1).expand(-1, -1, e.shape[-1])) for e, (q, _, _) in jobs], 1)  # [B, sum M, C]
-        pred = torch.einsum("bmc,bchw->bmhw", rows.to(feat.dtype), feat)
+        pred = ops.mask_logits_rows(rows, feat)
         stats = ops.mask_row_stats(pred.reshape(B, total, Hm * Wm), tgt.reshape(B, G, Hm * Wm), alpha).view(B, total // G, G, 3)
         done, g0 = {}, 0
         for e, (_, _, groups) in jobs:

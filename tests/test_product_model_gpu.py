@@ -381,4 +381,4 @@ def test_mask_heads_batched_into_one_gemm_match_the_per_head_form(hip_lib, monke
         # through the random-weight net): the global bound only guards against a wrong term
         assert diff <= 2e-2 * float(g0[n].norm()) + 1e-4 * gmax, (n, diff, float(g0[n].norm()), gmax)
     for n in ("decoder.mask_head.layers.2.weight", "decoder.pixel_decoder.upconv.weight", "decoder.pixel_decoder.lateral.0.weight"):
-        assert _rel(g1[n], g0[n].cpu()) < 1e-3, n  # the parameters right behind the batched GEMM
+        assert _rel(g1[n], g0[n].cpu()) < 5e-3, n  # the parameters right behind the batched GEMM (run-to-run noise: ~1e-3)

@@ -6,8 +6,9 @@ from torch.profiler import profile, ProfilerActivity
 from dfine_seg_amd.synth import synthetic_batch
 from dfine_seg_amd.train import TrainStep
 
-t = TrainStep("m", 80, False, (640, 640), "cuda", total_steps=1000, use_graph=False)
-images, targets = synthetic_batch(32, 640, 640, 80, 8, seed=42, device="cuda")
+seg = "--segment" in sys.argv  # python tools/aten_stacks.py [--segment]
+t = TrainStep("m", 80, seg, (640, 640), "cuda", total_steps=1000, use_graph=False)
+images, targets = synthetic_batch(32, 640, 640, 80, 8, with_masks=seg, seed=42, device="cuda")
 images = images.contiguous(memory_format=torch.channels_last)
 for _ in range(4):
     t.step(images, targets)
