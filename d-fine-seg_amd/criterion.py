@@ -158,6 +158,8 @@ class DFINECriterion(nn.Module):
         if "pred_mask_embed" not in out:
             return {}
         embed, feat = out["pred_mask_embed"], cache["mask_feat"]
+        if id(embed) in cache.get("mask_losses", {}):  # every head at once: _batched_mask_stats
+            return cache["mask_losses"][id(embed)]
         q, valid, groups = slots
         B, M = q.shape
         Hm, Wm = feat.shape[-2:]
@@ -167,16 +169,9 @@ class DFINECriterion(nn.Module):
         tgt, fg = cache["mask_targets"], cache["mask_fg"]
         G = tgt.shape[1]
         alpha = 0.5 + 0.25 * (1 - 2 * fg).clamp(-1, 1)  # [B, G]
-        batched = cache.get("mask_stats", {}).get(id(embed))  # all heads' logits formed by ONE GEMM (_batched_mask_stats)
-        if batched is None:
-            rows = embed.gather(1, q.unsqueeze(-1).expand(-1, -1, embed.shape[-1]))  # [B, M, C]
-            pred = ops.mask_logits_rows(rows, feat)  # [B, M, Hm, Wm], M = groups * G
-        if batched is not None:
-            stats = batched  # [B, groups, G, 3]
-            focal = stats[..., 0] / float(Hm * Wm)
-            inter, psum = stats[..., 1], stats[..., 2]
-            tsum = (fg * float(Hm * Wm)).unsqueeze(1)
-        elif self.fused and pred.is_cuda and (Hm * Wm) % 8 == 0 and B * M <= 65535:
+        rows = embed.gather(1, q.unsqueeze(-1).expand(-1, -1, embed.shape[-1]))  # [B, M, C]
+        pred = ops.mask_logits_rows(rows, feat)  # [B, M, Hm, Wm], M = groups * G
+        if self.fused and pred.is_cuda and (Hm * Wm) % 8 == 0 and B * M <= 65535:
             # HIP: per-row sums of the focal terms, p*t and p in one pass (and one pass backward)
             stats = ops.mask_row_stats(pred.reshape(B, M, Hm * Wm), tgt.reshape(B, G, Hm * Wm), alpha).view(B, groups, G, 3)
             focal = stats[..., 0] / float(Hm * Wm)
@@ -203,7 +198,7 @@ class DFINECriterion(nn.Module):
         output), which reads the [B, C, H/4, W/4] feature map once per head forward and twice backward and leaves autograd
         to add the heads' feature-map gradients one by one (8 heads at 640^2: 7 adds over a 420 MB map). Rows of all heads
         are concatenated along M (row m still belongs to ground truth m % G), so the per-row results are the same numbers.
-        Fills cache["mask_stats"][id(embed)] = [B, groups, G, 3] per head; leaves it empty when the fused kernel does not
+        Fills cache["mask_losses"][id(embed)] = the head's two loss terms; leaves it empty when the fused kernel does not
         apply (the per-head path then runs)."""
         feat = cache["mask_feat"]
         jobs = [(out["pred_mask_embed"], pairs) for out, pairs in jobs if pairs is not None and "pred_mask_embed" in out]
@@ -223,11 +218,24 @@ class DFINECriterion(nn.Module):
         rows = torch.cat([e.gather(1, q.unsqueeze(-1).expand(-1, -1, e.shape[-1])) for e, (q, _, _) in jobs], 1)  # [B, sum M, C]
         pred = ops.mask_logits_rows(rows, feat)
         stats = ops.mask_row_stats(pred.reshape(B, total, Hm * Wm), tgt.reshape(B, G, Hm * Wm), alpha).view(B, total // G, G, 3)
-        done, g0 = {}, 0
-        for e, (_, _, groups) in jobs:
-            done[id(e)] = stats[:, g0 : g0 + groups]
+        # ... and the small tail (dice ratio, means over the matched pairs) for all heads in one set of [B, sum groups, G]
+        # operations: per head it is ~15 launches forward and ~25 backward of a few hundred elements each
+        focal = stats[..., 0] / float(Hm * Wm)
+        inter, psum = stats[..., 1], stats[..., 2]
+        tsum = (fg * float(Hm * Wm)).unsqueeze(1)
+        dice = 1.0 - (2.0 * inter + 1e-6) / (psum + tsum + 1e-6)
+        w = torch.cat([valid.view(B, groups, G) for _, (_, valid, groups) in jobs], 1).float()  # [B, sum groups, G]
+        onehot = torch.zeros(total // G, len(jobs), dtype=torch.float32, device=feat.device)  # [sum groups, heads]; device-side
+        g0 = 0                                                                                 # fills only: capturable
+        for i, (_, (_, _, groups)) in enumerate(jobs):
+            onehot[g0 : g0 + groups, i] = 1.0
             g0 += groups
-        cache["mask_stats"] = done
+        per_group = torch.stack([(focal * w).sum((0, 2)), (dice * w).sum((0, 2)), w.sum((0, 2))], 0)  # [3, sum groups]
+        per_head = per_group @ onehot  # [3, heads]
+        n = per_head[2].clamp(min=1)  # mean over the matched pairs, like the reference's .mean() over gathered rows
+        live = (per_head[2] > 0).float()
+        bce, dice_h = (per_head[0] / n * live).unbind(0), (per_head[1] / n * live).unbind(0)
+        cache["mask_losses"] = {id(e): {"loss_mask_bce": bce[i], "loss_mask_dice": dice_h[i]} for i, (e, _) in enumerate(jobs)}
 
     # ------------------------------------------------------------------ forward
     @staticmethod
