@@ -1,6 +1,7 @@
 """Benchmark of the D-FINE training hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W            (N=1)
+    python bench.py --gpus N ...                              (N>1: starts N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = forward (bf16 autocast) + criterion with device-side Hungarian matching + backward
@@ -120,8 +121,51 @@ def load_pmc_traffic():
         return json.load(f), "profiles/" + os.path.basename(files[-1])
 
 
+def spawn_ranks(n_ranks):
+    """`python bench.py --gpus N` with no torchrun environment: start N rank processes of this same script (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would, rendezvous on 127.0.0.1) BEFORE this
+    process has touched the GPU, relay rank 0's stdout (its single JSON line) and exit with the ranks' status. The reference
+    starts its ranks with `torchrun --nproc_per_node=N` (Makefile:21-23); this is that launcher for the driver's plain
+    command shape. DFINE_BENCH_WORKER names another worker script (tests use a stub)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    worker = os.environ.get("DFINE_BENCH_WORKER", os.path.abspath(__file__))
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+        # rank 0 inherits this process's stdout; the other ranks' stdout goes to stderr so exactly one line reaches stdout
+        procs.append(subprocess.Popen([sys.executable, worker] + sys.argv[1:], env=env, stdout=None if r == 0 else sys.stderr))
+    rc, kill_at = 0, None
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:  # a dead rank leaves the others waiting in a collective: end them (exact PIDs)
+                    q.terminate()
+                kill_at = time.monotonic() + 20
+        if kill_at is not None and time.monotonic() > kill_at:
+            for q in alive:
+                q.kill()
+            kill_at = None
+        time.sleep(0.05)
+    return rc if rc > 0 else (1 if rc else 0)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to stdout when the first communicator is
     # created, so everything else this process writes to fd 1 is sent to stderr and the JSON goes to the saved descriptor
     sys.stdout.flush()

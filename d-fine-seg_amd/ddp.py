@@ -194,6 +194,29 @@ class FlatGradAllReduce:
         self.flat.grads.zero_()
 
 
+def stage_runs(entries, prefixes):
+    """Contiguous [begin, end) ranges of the flat layout per stage. Every entry must belong to exactly one stage (by name
+    prefix); a run is a maximal sequence of NEIGHBOURS in offset order that share a stage, so the alignment padding between
+    two of them rides along but no other stage's parameter ever lies inside a run (a foreign 1-element LAB scale between two
+    same-stage tensors would otherwise be all-reduced on the side stream while its own stage is still writing it)."""
+    def stage_of(name):
+        hits = [i for i, p in enumerate(prefixes) if name.startswith(p)]
+        if len(hits) != 1:
+            raise RuntimeError(f"StagedGradAllReduce: parameter {name!r} belongs to {len(hits)} of the stages {prefixes}")
+        return hits[0]
+
+    runs = [[] for _ in prefixes]
+    prev_stage = None
+    for name, _, off, n, _ in sorted(entries, key=lambda e: e[2]):
+        s = stage_of(name)
+        if s == prev_stage:
+            runs[s][-1][1] = off + n
+        else:
+            runs[s].append([off, off + n])
+        prev_stage = s
+    return [[tuple(r) for r in rs] for rs in runs]
+
+
 class StagedGradAllReduce(FlatGradAllReduce):
     """The north-star schedule WITH graphs: backward is captured as three hipGraphs cut at the module boundaries
     (criterion + decoder | encoder | backbone); as soon as a stage's graph has been enqueued, the contiguous ranges of the
@@ -218,19 +241,8 @@ class StagedGradAllReduce(FlatGradAllReduce):
             self.stage_prefixes = tuple(stage_prefixes)
         self.on_gpu = self.flat.device.type == "cuda"
         self.side_stream = torch.cuda.Stream(self.flat.device) if self.on_gpu else None
-        self.stage_ranges = []
-        for prefix in self.stage_prefixes:
-            runs = []
-            for name, p, off, n, _ in sorted((e for e in self.flat.entries if e[0].startswith(prefix)), key=lambda e: e[2]):
-                if runs and off - runs[-1][1] < 64:  # alignment padding between neighbours: keep one run
-                    runs[-1][1] = off + n
-                else:
-                    runs.append([off, off + n])
-            self.stage_ranges.append([self.flat.grads[a:b] for a, b in runs])
-        covered = sum(t.numel() for rs in self.stage_ranges for t in rs)
-        owned = sum(e[3] for e in self.flat.entries)
-        if covered < owned:
-            raise RuntimeError("StagedGradAllReduce: a trainable parameter belongs to none of decoder / encoder / backbone")
+        self.stage_ranges = [[self.flat.grads[a:b] for a, b in runs]
+                             for runs in stage_runs(self.flat.entries, self.stage_prefixes)]
 
     def reduce_stage(self, stage):
         """All-reduce the gradient ranges of ``stage`` on the side stream, after the work enqueued so far on the

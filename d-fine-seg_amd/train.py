@@ -235,6 +235,9 @@ class TrainStep:
         self.optimizer.launch()  # clip + AdamW + EMA(params) + bf16 shadow + zero grads
         if self.ema is not None:
             self.ema.update_buffers(self.optimizer.hyper[6])
+        # ... and so is this step's claim on the scratch arena: an op called outside a TrainStep (or by another TrainStep's
+        # replayed graph, which dirties the arena without moving ``used``) must get its own zeroed workspace
+        ops.zero_arena = None
 
     def _body(self, images, tb, inject=None):
         loss = self._forward_backward(images, tb, inject)
@@ -304,6 +307,10 @@ class TrainStep:
         if s_tb.mask_tgt is not None:
             s_tb.mask_tgt.copy_(tb.mask_tgt, non_blocking=True)
         graph.replay()
+        from . import ops
+
+        ops.zero_arena = None  # the replay wrote this step's arena; nothing outside the graph may take "pre-zeroed" slices of it
+        ops.wgrad_queue = None
         for m in self._conv_norms:  # host-side batch counters the replay does not run
             m._pending_batches += 1
         return s_loss
