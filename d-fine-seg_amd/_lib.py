@@ -39,6 +39,11 @@ SIGNATURES = {
     "dfine_stem_pool_bwd": [_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p] + [_c_int] * 4 + [_c_void_p],
     "dfine_mask_loss_stats": [_c_void_p, _c_int] + [_c_void_p] * 3 + [_c_int] * 4 + [_c_void_p],
     "dfine_mask_loss_grad": [_c_void_p, _c_int] + [_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p],
+    "dfine_bn_pair_act_fwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] * 2 + [_c_int, _c_void_p],
+    "dfine_bn_pair_act_bwd": [_c_void_p] * 3 + [_c_int, _c_void_p, _c_int, _c_int] + [_c_void_p] * 13 + [_c_int] * 4 + [ctypes.c_float, _c_void_p],
+    "dfine_mask_rows_stats": [_c_void_p] * 5 + [_c_int] * 5 + [_c_void_p],
+    "dfine_mask_rows_dz": [_c_void_p] * 6 + [_c_int] * 6 + [_c_void_p],
+    "dfine_mask_rows_dfeat": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p] + [_c_int] * 4 + [_c_void_p],
     "dfine_add_layernorm_fwd": [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 6 + [ctypes.c_longlong, _c_int, ctypes.c_float, ctypes.c_float, _c_void_p],
     "dfine_add_layernorm_bwd": [_c_void_p, _c_void_p, _c_int] + [_c_void_p] * 6 + [ctypes.c_longlong, _c_int, ctypes.c_float, _c_void_p],
     "dfine_grad_sumsq": [_c_void_p, ctypes.c_longlong, _c_void_p, _c_void_p],
@@ -68,7 +73,7 @@ SIGNATURES = {
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int, _c_void_p, _c_int, _c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 _lib = None
 
 IGEMM_MAX_TAPS = 16

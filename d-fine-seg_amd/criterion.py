@@ -216,8 +216,11 @@ class DFINECriterion(nn.Module):
         G = tgt.shape[1]
         alpha = 0.5 + 0.25 * (1 - 2 * fg).clamp(-1, 1)
         rows = torch.cat([e.gather(1, q.unsqueeze(-1).expand(-1, -1, e.shape[-1])) for e, (q, _, _) in jobs], 1)  # [B, sum M, C]
-        pred = ops.mask_logits_rows(rows, feat)
-        stats = ops.mask_row_stats(pred.reshape(B, total, Hm * Wm), tgt.reshape(B, G, Hm * Wm), alpha).view(B, total // G, G, 3)
+        if ops.mask_rows_loss_supported(rows, feat):  # GEMM + row statistics in one kernel: the logits are never written
+            stats = ops.mask_rows_loss(rows, feat, tgt.reshape(B, G, Hm * Wm), alpha).view(B, total // G, G, 3)
+        else:
+            pred = ops.mask_logits_rows(rows, feat)
+            stats = ops.mask_row_stats(pred.reshape(B, total, Hm * Wm), tgt.reshape(B, G, Hm * Wm), alpha).view(B, total // G, G, 3)
         # ... and the small tail (dice ratio, means over the matched pairs) for all heads in one set of [B, sum groups, G]
         # operations: per head it is ~15 launches forward and ~25 backward of a few hundred elements each
         focal = stats[..., 0] / float(Hm * Wm)

@@ -415,6 +415,10 @@ static int ig_dispatch_g(const void* A, const void* Bw, void* C, const float* bi
                   : ig_dispatch_k<VEC, OVEC, false>(A, Bw, C, bias, stats, g, stream);
 }
 
+// igemm2.hip: the LDS-DMA ring body for operands on the 16-byte path
+int igemm2_run(const void* A, const void* Bw, void* C, const float* bias, double* stats, const IGemmGeom& g,
+               long long a_extent, bool ovec8, hipStream_t st);
+
 }  // namespace dfine
 
 using namespace dfine;
@@ -456,6 +460,16 @@ extern "C" int dfine_igemm_bf16(const void* A, const void* Bw, void* C, const fl
   else if (unit % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 && pa % 8 == 0 && pb % 8 == 0) vec = 4;
   const bool ovec8 = g.ldc % 8 == 0 && pc % 16 == 0;
   hipStream_t st = (hipStream_t)stream;
+  // Which body: the LDS-DMA ring (igemm2.hip) for plain rows (1x1 convs, Linears: 5-18 % faster on this model's shapes,
+  // tools/bench_igemm_cfg.py), the register-staged one below for gathers (it wins on the 40x40 / 20x20 maps and ties on
+  // 80x80). DFINE_IGEMM_V=1 / 2 forces one body for every launch (A/B measurements).
+  const char* fb = getenv("DFINE_IGEMM_V");  // read per call: tools/bench_igemm_cfg.py switches it at run time
+  const int forced_body = fb ? atoi(fb) : 0;
+  const bool use_v2 = forced_body == 2 || (forced_body != 1 && !g.gather);
+  if (vec == 8 && use_v2) {
+    const int rc = igemm2_run(A, Bw, C, bias, stats, g, a_extent, ovec8, st);
+    if (rc != DFINE_E_UNSUPPORTED) return rc;
+  }
   if (vec == 8) return ovec8 ? ig_dispatch_g<8, 8>(A, Bw, C, bias, stats, g, st) : ig_dispatch_g<8, 1>(A, Bw, C, bias, stats, g, st);
   if (vec == 4) return ovec8 ? ig_dispatch_g<4, 8>(A, Bw, C, bias, stats, g, st) : ig_dispatch_g<4, 1>(A, Bw, C, bias, stats, g, st);
   return ovec8 ? ig_dispatch_g<1, 8>(A, Bw, C, bias, stats, g, st) : ig_dispatch_g<1, 1>(A, Bw, C, bias, stats, g, st);

@@ -12,30 +12,13 @@
 // Forward: one workgroup per row, 16-byte loads, wave shuffle + LDS reduction, no atomics.
 // Target slot m of image b is ground truth m % G (M = groups * G): the denoising groups share targets.
 #include "common.h"
+#include "maskmath.h"
 
 namespace dfine {
 
 struct MaskGeom {
   int M, G, HW;
 };
-
-// sigmoid and softplus from ONE exponential: e = exp(-|z|), p = (z >= 0 ? 1 : e) / (1 + e), softplus = max(z, 0) + log(1 + e)
-__device__ __forceinline__ void sigmoid_softplus(float z, float& p, float& softplus) {
-  const float e = __expf(-fabsf(z));
-  const float r = __frcp_rn(1.f + e);
-  p = z >= 0.f ? r : e * r;
-  softplus = fmaxf(z, 0.f) + __logf(1.f + e);
-}
-
-__device__ __forceinline__ void mask_terms(float z, float t, float alpha, float& focal, float& p_out) {
-  float p, sp;
-  sigmoid_softplus(z, p, sp);
-  const float bce = sp - z * t;                 // softplus(z) - z t
-  const float one_m_pt = p + t - 2.f * p * t;   // 1 - p_t
-  const float a_t = alpha * t + (1.f - alpha) * (1.f - t);
-  focal = a_t * one_m_pt * one_m_pt * bce;
-  p_out = p;
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void mask_stats_kernel(const T* __restrict__ logits, const float* __restrict__ tgt,
@@ -91,16 +74,7 @@ __global__ __launch_bounds__(256) void mask_grad_kernel(const T* __restrict__ lo
   for (int k = 0; k < V; k += 4) load_vec<float, 4>(t + k, tt + k);
 #pragma unroll
   for (int k = 0; k < V; ++k) {
-    const float z = zz[k], tk = tt[k];
-    float p, sp;
-    sigmoid_softplus(z, p, sp);
-    const float pq = p * (1.f - p);
-    const float bce = sp - z * tk;
-    const float one_m_pt = p + tk - 2.f * p * tk;
-    const float a_t = a * tk + (1.f - a) * (1.f - tk);
-    // d(1 - p_t)/dz = (1 - 2t) p (1-p);  d bce/dz = p - t
-    const float dfocal = a_t * (2.f * one_m_pt * (1.f - 2.f * tk) * pq * bce + one_m_pt * one_m_pt * (p - tk));
-    out[k] = g0 * dfocal + (g1 * tk + g2) * pq;
+    out[k] = mask_dz(zz[k], tt[k], a, g0, g1, g2);
   }
   store_vec<T, V>(d_logits + (size_t)row * g.HW + i, out);
 }

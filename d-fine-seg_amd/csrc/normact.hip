@@ -380,24 +380,277 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
   }
 }
 
-static int apply_target_blocks() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("DFINE_BN_APPLY_BLOCKS");
-    v = e ? atoi(e) : 1024;
-    if (v < 64) v = 64;
+
+// ---------------------------------------------------------------------------------------------------------------
+// Two norms summed under one activation:  y = act( bn_a(xa) + bn_b(xb) )  -- RepVgg's training form
+// silu(norm(conv3x3(x)) + norm(conv1x1(x))) (reference hybrid_encoder.py:106-121). As two single-norm calls the
+// second branch's output is written, re-read as the first's addend, and in backward the shared dz travels through
+// memory as `dadd`: 4 + 4 launches and 13 map passes backward. Here: 1 launch forward (xa, xb -> y), 2 backward
+// (reduce: xa, xb, dy -> 3 sums per channel; dx: xa, xb, dy -> dxa, dxb), 8 passes.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_pair_apply_kernel(
+    const T* __restrict__ xa, const T* __restrict__ xb, T* __restrict__ y, const double* __restrict__ sums_a,
+    const double* __restrict__ sums_b, const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
+    const float* __restrict__ gamma_b, const float* __restrict__ beta_b, float* __restrict__ rm_a, float* __restrict__ rv_a,
+    float* __restrict__ rm_b, float* __restrict__ rv_b, float* __restrict__ save_a, float* __restrict__ save_b, NaGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float cst[];  // [3][lanes]: scale_a, scale_b, shift_a + shift_b
+  const int lanes = blockDim.x * VEC;
+  const int cbase = blockIdx.y * lanes;
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  for (int k = tid; k < lanes; k += blockDim.x * blockDim.y) {
+    const int c = cbase + k;
+    float sc[2], sh[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const double* sums = w ? sums_b : sums_a;
+      float* rm = w ? rm_b : rm_a;
+      float* rv = w ? rv_b : rv_a;
+      float* save = w ? save_b : save_a;  // [2][C]: mean, rstd
+      float mean, rstd;
+      if (g.training) {
+        double s1 = 0, s2 = 0;
+#pragma unroll
+        for (int rep = 0; rep < NA_REPLICAS; ++rep) {
+          s1 += sums[(size_t)rep * 2 * g.C + c];
+          s2 += sums[(size_t)rep * 2 * g.C + g.C + c];
+        }
+        const double m = s1 / g.n_pix;
+        double v = s2 / g.n_pix - m * m;
+        if (v < 0) v = 0;
+        mean = (float)m;
+        const float var = (float)v;
+        rstd = rsqrtf(var + g.eps);
+        if (blockIdx.x == 0) {
+          save[c] = mean;
+          save[g.C + c] = rstd;
+          const float unbiased = g.n_pix > 1 ? var * ((float)g.n_pix / (float)(g.n_pix - 1)) : var;
+          rm[c] = (1.f - g.momentum) * rm[c] + g.momentum * mean;
+          rv[c] = (1.f - g.momentum) * rv[c] + g.momentum * unbiased;
+        }
+      } else {
+        mean = rm[c];
+        rstd = rsqrtf(rv[c] + g.eps);
+      }
+      sc[w] = rstd * (w ? gamma_b : gamma_a)[c];
+      sh[w] = (w ? beta_b : beta_a)[c] - mean * sc[w];
+    }
+    cst[k] = sc[0];
+    cst[lanes + k] = sc[1];
+    cst[2 * lanes + k] = sh[0] + sh[1];
   }
-  return v;
+  __syncthreads();
+  const int c0 = cbase + threadIdx.x * VEC;
+  float sa[VEC], sb[VEC], sh[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    sa[i] = cst[threadIdx.x * VEC + i];
+    sb[i] = cst[lanes + threadIdx.x * VEC + i];
+    sh[i] = cst[2 * lanes + threadIdx.x * VEC + i];
+  }
+  const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
+  for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL) {
+    PackedVec<T, VEC> pa[DFINE_NA_UNROLL], pb[DFINE_NA_UNROLL];
+    bool ok[DFINE_NA_UNROLL];
+#pragma unroll
+    for (int u = 0; u < DFINE_NA_UNROLL; ++u) {
+      const int pix = first + (n + u) * blockDim.y;
+      ok[u] = n + u < g.pix_per_thread && pix < g.n_pix;
+      if (ok[u]) {
+        pa[u].load(xa + (size_t)pix * g.C + c0);
+        pb[u].load(xb + (size_t)pix * g.C + c0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < DFINE_NA_UNROLL; ++u) {
+      if (!ok[u]) continue;
+      float va[VEC], vb[VEC];
+      pa[u].unpack(va);
+      pb[u].unpack(vb);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) va[i] = act_fwd(va[i] * sa[i] + vb[i] * sb[i] + sh[i], g.act);
+      store_vec<T, VEC>(y + (size_t)(first + (n + u) * blockDim.y) * g.ldy + c0, va);
+    }
+  }
+}
+
+// backward pass 1 of the pair: per channel sum(dz), sum(dz * xhat_a), sum(dz * xhat_b)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_pair_bwd_reduce_kernel(
+    const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ dy, const T* __restrict__ dy2,
+    const float* __restrict__ save_a, const float* __restrict__ save_b, const float* __restrict__ gamma_a,
+    const float* __restrict__ beta_a, const float* __restrict__ gamma_b, const float* __restrict__ beta_b,
+    double* __restrict__ red_out, NaGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int lanes = blockDim.x * VEC;
+  const int cbase = blockIdx.y * lanes;
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  for (int k = tid; k < lanes; k += blockDim.x * blockDim.y) {
+    const int c = cbase + k;
+    red[k] = save_a[c];
+    red[lanes + k] = save_a[g.C + c];
+    red[2 * lanes + k] = save_b[c];
+    red[3 * lanes + k] = save_b[g.C + c];
+    red[4 * lanes + k] = gamma_a[c];
+    red[5 * lanes + k] = gamma_b[c];
+    red[6 * lanes + k] = beta_a[c] + beta_b[c];
+  }
+  __syncthreads();
+  float mean_a[VEC], rstd_a[VEC], mean_b[VEC], rstd_b[VEC], gam_a[VEC], gam_b[VEC], bet[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int k = threadIdx.x * VEC + i;
+    mean_a[i] = red[k], rstd_a[i] = red[lanes + k], mean_b[i] = red[2 * lanes + k], rstd_b[i] = red[3 * lanes + k];
+    gam_a[i] = red[4 * lanes + k], gam_b[i] = red[5 * lanes + k], bet[i] = red[6 * lanes + k];
+  }
+  __syncthreads();  // `red` is reused by the column reduction below
+  const int c0 = cbase + threadIdx.x * VEC;
+  float acc[3][VEC];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[q][i] = 0.f;
+  const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
+  for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL_BWD) {
+    PackedVec<T, VEC> pa[DFINE_NA_UNROLL_BWD], pb[DFINE_NA_UNROLL_BWD], pd[DFINE_NA_UNROLL_BWD], pe[DFINE_NA_UNROLL_BWD];
+    bool ok[DFINE_NA_UNROLL_BWD];
+#pragma unroll
+    for (int u = 0; u < DFINE_NA_UNROLL_BWD; ++u) {
+      const int pix = first + (n + u) * blockDim.y;
+      ok[u] = n + u < g.pix_per_thread && pix < g.n_pix;
+      if (ok[u]) {
+        pa[u].load(xa + (size_t)pix * g.C + c0);
+        pb[u].load(xb + (size_t)pix * g.C + c0);
+        pd[u].load(dy + (size_t)pix * g.ld_dy + c0);
+        if (dy2) pe[u].load(dy2 + (size_t)pix * g.ld_dy2 + c0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < DFINE_NA_UNROLL_BWD; ++u) {
+      if (!ok[u]) continue;
+      float va[VEC], vb[VEC], d[VEC];
+      pa[u].unpack(va);
+      pb[u].unpack(vb);
+      pd[u].unpack(d);
+      if (dy2) {
+        float d2[VEC];
+        pe[u].unpack(d2);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) d[i] += d2[i];
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float ha = (va[i] - mean_a[i]) * rstd_a[i], hb = (vb[i] - mean_b[i]) * rstd_b[i];
+        const float dz = d[i] * act_grad(ha * gam_a[i] + hb * gam_b[i] + bet[i], g.act);
+        acc[0][i] += dz;
+        acc[1][i] += dz * ha;
+        acc[2][i] += dz * hb;
+      }
+    }
+  }
+  ColReduce<T, 3>::template run<VEC>(acc, red, red_out, g.C, c0);
+}
+
+// backward pass 2 of the pair: dxa, dxb; block row 0 publishes dgamma / dbeta of both norms
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void bn_pair_bwd_dx_kernel(
+    const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ dy, const T* __restrict__ dy2,
+    const float* __restrict__ save_a, const float* __restrict__ save_b, const float* __restrict__ gamma_a,
+    const float* __restrict__ beta_a, const float* __restrict__ gamma_b, const float* __restrict__ beta_b,
+    const double* __restrict__ red_in, T* __restrict__ dxa, T* __restrict__ dxb, float* __restrict__ dgamma_a,
+    float* __restrict__ dbeta_a, float* __restrict__ dgamma_b, float* __restrict__ dbeta_b, NaGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float cst[];  // [10][lanes]
+  const int lanes = blockDim.x * VEC;
+  const int cbase = blockIdx.y * lanes;
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  const float inv_n = 1.f / (float)g.n_pix;
+  for (int k = tid; k < lanes; k += blockDim.x * blockDim.y) {
+    const int c = cbase + k;
+    double r0 = 0, r1 = 0, r2 = 0;
+#pragma unroll
+    for (int rep = 0; rep < NA_REPLICAS; ++rep) {
+      const double* rr = red_in + (size_t)rep * 3 * g.C;
+      r0 += rr[c]; r1 += rr[g.C + c]; r2 += rr[2 * g.C + c];
+    }
+    cst[k] = save_a[c];
+    cst[lanes + k] = save_a[g.C + c];
+    cst[2 * lanes + k] = save_b[c];
+    cst[3 * lanes + k] = save_b[g.C + c];
+    cst[4 * lanes + k] = gamma_a[c];
+    cst[5 * lanes + k] = gamma_b[c];
+    cst[6 * lanes + k] = beta_a[c] + beta_b[c];
+    cst[7 * lanes + k] = g.training ? (float)r0 * inv_n : 0.f;
+    cst[8 * lanes + k] = g.training ? (float)r1 * inv_n : 0.f;
+    cst[9 * lanes + k] = g.training ? (float)r2 * inv_n : 0.f;
+    if (blockIdx.x == 0) {  // one writer per channel: accumulate (the caller may point these at .grad)
+      dgamma_a[c] += (float)r1;
+      dgamma_b[c] += (float)r2;
+      dbeta_a[c] += (float)r0;
+      dbeta_b[c] += (float)r0;
+    }
+  }
+  __syncthreads();
+  float mean_a[VEC], rstd_a[VEC], mean_b[VEC], rstd_b[VEC], gam_a[VEC], gam_b[VEC], bet[VEC], m_dz[VEC], m_a[VEC], m_b[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int k = threadIdx.x * VEC + i;
+    mean_a[i] = cst[k], rstd_a[i] = cst[lanes + k], mean_b[i] = cst[2 * lanes + k], rstd_b[i] = cst[3 * lanes + k];
+    gam_a[i] = cst[4 * lanes + k], gam_b[i] = cst[5 * lanes + k], bet[i] = cst[6 * lanes + k];
+    m_dz[i] = cst[7 * lanes + k], m_a[i] = cst[8 * lanes + k], m_b[i] = cst[9 * lanes + k];
+  }
+  const int c0 = cbase + threadIdx.x * VEC;
+  const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
+  for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL_BWD) {
+    PackedVec<T, VEC> pa[DFINE_NA_UNROLL_BWD], pb[DFINE_NA_UNROLL_BWD], pd[DFINE_NA_UNROLL_BWD], pe[DFINE_NA_UNROLL_BWD];
+    bool ok[DFINE_NA_UNROLL_BWD];
+#pragma unroll
+    for (int u = 0; u < DFINE_NA_UNROLL_BWD; ++u) {
+      const int pix = first + (n + u) * blockDim.y;
+      ok[u] = n + u < g.pix_per_thread && pix < g.n_pix;
+      if (ok[u]) {
+        pa[u].load(xa + (size_t)pix * g.C + c0);
+        pb[u].load(xb + (size_t)pix * g.C + c0);
+        pd[u].load(dy + (size_t)pix * g.ld_dy + c0);
+        if (dy2) pe[u].load(dy2 + (size_t)pix * g.ld_dy2 + c0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < DFINE_NA_UNROLL_BWD; ++u) {
+      if (!ok[u]) continue;
+      const size_t off = (size_t)(first + (n + u) * blockDim.y) * g.C + c0;
+      float va[VEC], vb[VEC], d[VEC];
+      pa[u].unpack(va);
+      pb[u].unpack(vb);
+      pd[u].unpack(d);
+      if (dy2) {
+        float d2[VEC];
+        pe[u].unpack(d2);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) d[i] += d2[i];
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float ha = (va[i] - mean_a[i]) * rstd_a[i], hb = (vb[i] - mean_b[i]) * rstd_b[i];
+        const float dz = d[i] * act_grad(ha * gam_a[i] + hb * gam_b[i] + bet[i], g.act);
+        va[i] = gam_a[i] * rstd_a[i] * (dz - m_dz[i] - ha * m_a[i]);
+        vb[i] = gam_b[i] * rstd_b[i] * (dz - m_dz[i] - hb * m_b[i]);
+      }
+      store_vec<T, VEC>(dxa + off, va);
+      store_vec<T, VEC>(dxb + off, vb);
+    }
+  }
+}
+
+static int apply_target_blocks() {  // read per call: tools/bench_bn.py switches the knobs at run time
+  const char* e = getenv("DFINE_BN_APPLY_BLOCKS");
+  const int v = e ? atoi(e) : 1024;
+  return v < 64 ? 64 : v;
 }
 
 static int reduce_target_blocks() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("DFINE_BN_REDUCE_BLOCKS");
-    v = e ? atoi(e) : 512;
-    if (v < 64) v = 64;
-  }
-  return v;
+  const char* e = getenv("DFINE_BN_REDUCE_BLOCKS");
+  const int v = e ? atoi(e) : 512;
+  return v < 64 ? 64 : v;
 }
 
 struct NaLaunch {
@@ -471,8 +724,11 @@ static int bwd_impl(const void* x, const void* addend, const void* dy, int ld_dy
   g.ld_dy = ld_dy, g.ld_dy2 = ld_dy2;
   if (phase != 2) {
     const size_t lds = (size_t)R.block.y * 4 * R.block.x * VEC * sizeof(float);
-    static const int unroll = getenv("DFINE_BN_BWD_UNROLL") ? atoi(getenv("DFINE_BN_BWD_UNROLL")) : 2;
-    if (unroll == 4)
+    const int unroll = getenv("DFINE_BN_BWD_UNROLL") ? atoi(getenv("DFINE_BN_BWD_UNROLL")) : 2;
+    if (unroll == 8)
+      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, 8>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy, (const T*)dy2,
+                         save_mean, save_rstd, gamma, beta, lab_scale, red, g);
+    else if (unroll == 4)
       hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, 4>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy, (const T*)dy2,
                          save_mean, save_rstd, gamma, beta, lab_scale, red, g);
     else
@@ -484,6 +740,43 @@ static int bwd_impl(const void* x, const void* addend, const void* dy, int ld_dy
   g.pix_per_thread = A.ppt;
   hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VEC>), A.grid, A.block, (size_t)6 * A.block.x * VEC * sizeof(float), st, (const T*)x, (const T*)addend, (const T*)dy, (const T*)dy2, save_mean,
                      save_rstd, gamma, beta, lab_scale, red, (T*)dx, (T*)dadd, dgamma, dbeta, dlab_scale, dlab_bias, g);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int VEC>
+static int pair_fwd_impl(const void* xa, const void* xb, void* y, const double* sums_a, const double* sums_b, const float* gamma_a,
+                         const float* beta_a, const float* gamma_b, const float* beta_b, float* rm_a, float* rv_a, float* rm_b,
+                         float* rv_b, float* save_a, float* save_b, int n_pix, int C, int act, int training, float eps,
+                         float momentum, int ldy, hipStream_t st) {
+  NaLaunch A;
+  if (int rc = plan<VEC>(&A, n_pix, C, apply_target_blocks())) return rc;
+  NaGeom g = make_geom(n_pix, C, A.ppt, act, false, false, training, eps, momentum);
+  g.ldy = ldy;
+  hipLaunchKernelGGL((bn_pair_apply_kernel<T, VEC>), A.grid, A.block, (size_t)3 * A.block.x * VEC * sizeof(float), st, (const T*)xa,
+                     (const T*)xb, (T*)y, sums_a, sums_b, gamma_a, beta_a, gamma_b, beta_b, rm_a, rv_a, rm_b, rv_b, save_a, save_b, g);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int VEC>
+static int pair_bwd_impl(const void* xa, const void* xb, const void* dy, int ld_dy, const void* dy2, int ld_dy2, const float* save_a,
+                         const float* save_b, const float* gamma_a, const float* beta_a, const float* gamma_b, const float* beta_b,
+                         double* red, void* dxa, void* dxb, float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
+                         int n_pix, int C, int act, int training, float eps, hipStream_t st) {
+  NaLaunch R, A;
+  if (int rc = plan<VEC>(&R, n_pix, C, reduce_target_blocks())) return rc;
+  if (int rc = plan<VEC>(&A, n_pix, C, apply_target_blocks())) return rc;
+  NaGeom g = make_geom(n_pix, C, R.ppt, act, false, false, training, eps, 0.f);
+  g.ld_dy = ld_dy, g.ld_dy2 = ld_dy2;
+  const size_t lds_r = (size_t)R.block.x * VEC * sizeof(float) * (R.block.y * 3 > 7 ? R.block.y * 3 : 7);
+  hipLaunchKernelGGL((bn_pair_bwd_reduce_kernel<T, VEC>), R.grid, R.block, lds_r, st, (const T*)xa, (const T*)xb, (const T*)dy,
+                     (const T*)dy2, save_a, save_b, gamma_a, beta_a, gamma_b, beta_b, red, g);
+  DFINE_LAUNCH_CHECK();
+  g.pix_per_thread = A.ppt;
+  hipLaunchKernelGGL((bn_pair_bwd_dx_kernel<T, VEC>), A.grid, A.block, (size_t)10 * A.block.x * VEC * sizeof(float), st, (const T*)xa,
+                     (const T*)xb, (const T*)dy, (const T*)dy2, save_a, save_b, gamma_a, beta_a, gamma_b, beta_b, red, (T*)dxa, (T*)dxb,
+                     dgamma_a, dbeta_a, dgamma_b, dbeta_b, g);
   DFINE_LAUNCH_CHECK();
   return 0;
 }
@@ -555,4 +848,50 @@ extern "C" int dfine_bn_act_bwd(const void* x, const void* addend, const void* d
                         dlab_scale, dlab_bias, n_pix, C, act, training, eps, phase, st))
   DFINE_NA_DISPATCH(BWD);
 #undef BWD
+}
+
+extern "C" int dfine_bn_pair_act_fwd(const void* xa, const void* xb, void* y, int dtype, const double* sums_a, const double* sums_b,
+                                     const float* gamma_a, const float* beta_a, const float* gamma_b, const float* beta_b,
+                                     float* running_mean_a, float* running_var_a, float* running_mean_b, float* running_var_b,
+                                     float* save_a, float* save_b, int n_pix, int C, int act, int training, float eps, float momentum,
+                                     int ldy, void* stream) {
+  if (!xa || !xb || !y || !gamma_a || !beta_a || !gamma_b || !beta_b || !running_mean_a || !running_var_a || !running_mean_b ||
+      !running_var_b)
+    return DFINE_E_BADARG;
+  if (training && (!sums_a || !sums_b || !save_a || !save_b)) return DFINE_E_BADARG;
+  if (n_pix <= 0 || C <= 0 || act < 0 || act > 2) return DFINE_E_BADARG;
+  if (ldy == 0) ldy = C;
+  if (ldy < C) return DFINE_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int es = dtype == DFINE_DT_BF16 ? 2 : 4;
+#define PFWD(T, V)                                                                                                              \
+  ((ldy % V != 0 || (uintptr_t)y % (V * es) != 0)                                                                               \
+       ? DFINE_E_UNSUPPORTED                                                                                                    \
+       : pair_fwd_impl<T, V>(xa, xb, y, sums_a, sums_b, gamma_a, beta_a, gamma_b, beta_b, running_mean_a, running_var_a,          \
+                             running_mean_b, running_var_b, save_a, save_b, n_pix, C, act, training, eps, momentum, ldy, st))
+  DFINE_NA_DISPATCH(PFWD);
+#undef PFWD
+}
+
+extern "C" int dfine_bn_pair_act_bwd(const void* xa, const void* xb, const void* dy, int ld_dy, const void* dy2, int ld_dy2, int dtype,
+                                     const float* save_a, const float* save_b, const float* gamma_a, const float* beta_a,
+                                     const float* gamma_b, const float* beta_b, double* red, void* dxa, void* dxb, float* dgamma_a,
+                                     float* dbeta_a, float* dgamma_b, float* dbeta_b, int n_pix, int C, int act, int training,
+                                     float eps, void* stream) {
+  if (!xa || !xb || !dy || !save_a || !save_b || !gamma_a || !beta_a || !gamma_b || !beta_b || !red || !dxa || !dxb || !dgamma_a ||
+      !dbeta_a || !dgamma_b || !dbeta_b)
+    return DFINE_E_BADARG;
+  if (n_pix <= 0 || C <= 0 || act < 0 || act > 2) return DFINE_E_BADARG;
+  if (ld_dy == 0) ld_dy = C;
+  if (ld_dy2 == 0) ld_dy2 = C;
+  if (ld_dy < C || (dy2 && ld_dy2 < C)) return DFINE_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int es = dtype == DFINE_DT_BF16 ? 2 : 4;
+#define PBWD(T, V)                                                                                                                  \
+  ((ld_dy % V != 0 || (uintptr_t)dy % (V * es) != 0 || (dy2 && (ld_dy2 % V != 0 || (uintptr_t)dy2 % (V * es) != 0)))                \
+       ? DFINE_E_UNSUPPORTED                                                                                                        \
+       : pair_bwd_impl<T, V>(xa, xb, dy, ld_dy, dy2, ld_dy2, save_a, save_b, gamma_a, beta_a, gamma_b, beta_b, red, dxa, dxb, dgamma_a, \
+                             dbeta_a, dgamma_b, dbeta_b, n_pix, C, act, training, eps, st))
+  DFINE_NA_DISPATCH(PBWD);
+#undef PBWD
 }

@@ -183,13 +183,14 @@ class MaskPixelDecoder(nn.Module):
             y = y + addend if addend is not None else y
             return F.relu(y) if act == "relu" else y
         bf16_mode = torch.is_autocast_enabled() or x.dtype == torch.bfloat16
-        ws = ops.bn_workspace(conv.out_channels, x.device) if (bf16_mode and self.training) else None
+        batch_stats = self.training and bn.training  # a norm in .eval() inside a training model keeps its running statistics
+        ws = ops.bn_workspace(conv.out_channels, x.device) if (bf16_mode and batch_stats) else None
         stats = ws[: 32 * conv.out_channels] if ws is not None else None
         y = ops.conv_transpose2x2(x, conv.weight, stats) if transposed else ops.dense_conv(x, conv.weight, 1, 0, stats=stats)
-        if self.training:
+        if batch_stats:
             bn.num_batches_tracked.add_(1)
         return ops.batch_norm_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, act, addend=addend,
-                                  training=self.training, momentum=bn.momentum or 0.1, eps=bn.eps, ws=ws, have_stats=ws is not None)
+                                  training=batch_stats, momentum=bn.momentum or 0.1, eps=bn.eps, ws=ws, have_stats=ws is not None)
 
     def forward(self, feats, enc_s8):
         x = self._conv_bn(self.lateral[0], self.bn[0], feats[0])

@@ -44,7 +44,15 @@ class RepVgg(nn.Module):
             return ops.conv_bias_act(x, self.conv, "silu")
         if hasattr(self.conv1, "conv_bn_fused") or hasattr(self.conv2, "conv_bn_fused"):
             return self.conv1(x, addend=self.conv2(x), act="silu")
+        from . import ops
+
         (y3, ws3, hs3), (y1, ws1, hs1) = conv_pair(self.conv1, self.conv2, x)  # one input gradient for the two branches
+        n3, n1 = getattr(self.conv1, self.conv1.norm_name), getattr(self.conv2, self.conv2.norm_name)
+        if self.training and hs3 and hs1 and ops.batch_norm_pair_act_supported(y3, y1, n3, n1, ws3, ws1):
+            # both norms + the sum + SiLU in ONE launch (two backward): the 1x1 branch's output and the shared dz stay on chip
+            self.conv1._pending_batches += 1
+            self.conv2._pending_batches += 1
+            return ops.batch_norm_pair_act(y3, y1, n3, n1, "silu", ws3, ws1)
         return self.conv1._norm_tail(y3, ws3, hs3, addend=self.conv2._norm_tail(y1, ws1, hs1), act="silu")  # fused norm+add+silu
 
 
@@ -62,7 +70,8 @@ class CSP(nn.Module):
         if hasattr(self.conv1, "conv_bn_fused") or hasattr(self.conv2, "conv_bn_fused"):
             return self.bottlenecks(self.conv1(x)) + self.conv2(x)
         (ya, ws_a, hs_a), (yb, ws_b, hs_b) = conv_pair(self.conv1, self.conv2, x)
-        return self.bottlenecks(self.conv1._norm_tail(ya, ws_a, hs_a)) + self.conv2._norm_tail(yb, ws_b, hs_b)
+        # the branch sum rides in the second projection's norm kernel (``post``: added after the activation, one rounding)
+        return self.conv2._norm_tail(yb, ws_b, hs_b, post=self.bottlenecks(self.conv1._norm_tail(ya, ws_a, hs_a)))
 
 
 ELAN_BUFFER = os.environ.get("DFINE_ELAN_BUFFER", "1") != "0"  # measurement switch

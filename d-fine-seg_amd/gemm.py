@@ -66,6 +66,8 @@ def _launch(A, Bw, C, bias, stats, g, name, detail):
     lib = _lib.load()
     if _NO_PUBLISH:
         g.act |= int(_os.environ["DFINE_IGEMM_STATS_NOPUBLISH"]) << 8
+    if _os.environ.get("DFINE_IGEMM_DEBUG"):  # diagnostics of the LDS-DMA body: 8 = no MFMA, 16 = no DMA (tools/bench_igemm_cfg.py)
+        g.act |= int(_os.environ["DFINE_IGEMM_DEBUG"]) << 8
     _lib.require_gpu(A, Bw, C)
     nbytes = (g.M * (g.CI if g.gather else g.K) + g.M * g.N + g.N * g.K) * 2
     with _lib.timed(name, nbytes, detail, flops=2.0 * g.M * g.N * g.K):

@@ -125,7 +125,7 @@ class ConvNorm(nn.Module):
         """(ws, have_stats): the norm's workspace when the conv's epilogue is to leave the batch statistics in it."""
         norm = getattr(self, self.norm_name)
         bf16_mode = x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16)
-        if bf16_mode and self.training and isinstance(norm, nn.BatchNorm2d):
+        if bf16_mode and self.training and isinstance(norm, nn.BatchNorm2d) and norm.training:
             return ops.bn_workspace(self.conv.out_channels, x.device), True
         return None, False
 
@@ -157,7 +157,9 @@ class ConvNorm(nn.Module):
         conv = self.conv
         norm = getattr(self, self.norm_name)
         frozen = isinstance(norm, FrozenBatchNorm2d)
-        batch_stats = self.training and not frozen
+        # batch statistics as nn.BatchNorm2d decides: a norm put in .eval() inside a training model (frozen-statistics
+        # fine-tuning) normalises with its running statistics and leaves them alone
+        batch_stats = self.training and not frozen and norm.training
         act_name = act if act is not None else self.act_name
         lab = getattr(self, "lab", None)
         fused = (isinstance(norm, nn.BatchNorm2d) or frozen) and ops.batch_norm_act_supported(x, conv.out_channels)

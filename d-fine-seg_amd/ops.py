@@ -655,6 +655,99 @@ class _BatchNormAct(torch.autograd.Function):
                 dlab[1:2].to(lab_dtype) if ls32 is not None else None, None, None, None, None, None, None, None, dpost)
 
 
+class _BatchNormPairAct(torch.autograd.Function):
+    """y = act(bn_a(xa) + bn_b(xb)), both norms with batch statistics left by their convolutions' epilogues; see
+    include/dfine_hip.h (dfine_bn_pair_act_*)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, norm_a, norm_b, act, ws_a, ws_b, slot):
+        lib = _lib.load()
+        B, C, H, W = xa.shape
+        xal, xbl = _nhwc(xa), _nhwc(xb)
+        n_pix, ldy = B * H * W, 0
+        if slot is not None:
+            y = slot[0].buf[..., slot[1] : slot[1] + C]
+            ldy = slot[0].buf.shape[-1]
+        else:
+            y = torch.empty_like(xal)
+        ctx.slot = slot
+        ctx.set_materialize_grads(False)
+        ga, ba, gb, bb = (t.detach().float() for t in (norm_a.weight, norm_a.bias, norm_b.weight, norm_b.bias))
+        save_a, save_b = ws_a[32 * C : 34 * C], ws_b[32 * C : 34 * C]
+        with _lib.timed("bn_apply", 3 * xal.numel() * xal.element_size(), f"pair {n_pix}x{C}"):
+            rc = lib.dfine_bn_pair_act_fwd(_lib.ptr(xal), _lib.ptr(xbl), _lib.ptr(y), _lib.dtype_code(xal), _lib.ptr(ws_a), _lib.ptr(ws_b),
+                                           _lib.ptr(ga), _lib.ptr(ba), _lib.ptr(gb), _lib.ptr(bb), _lib.ptr(norm_a.running_mean),
+                                           _lib.ptr(norm_a.running_var), _lib.ptr(norm_b.running_mean), _lib.ptr(norm_b.running_var),
+                                           _lib.ptr(save_a), _lib.ptr(save_b), n_pix, C, _ACT_CODES[act], 1, float(norm_a.eps),
+                                           float(norm_a.momentum or 0.1), ldy, _lib.stream_ptr())
+        _lib.check(rc, "dfine_bn_pair_act_fwd")
+        ctx.save_for_backward(xal, xbl, ga, ba, gb, bb, save_a, save_b)
+        ctx.cfg = (act, float(norm_a.eps))
+        ctx.params = (norm_a.weight, norm_a.bias, norm_b.weight, norm_b.bias)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        xal, xbl, ga, ba, gb, bb, save_a, save_b = ctx.saved_tensors
+        act, eps = ctx.cfg
+        lib = _lib.load()
+        n_pix, C = xal.numel() // xal.shape[-1], xal.shape[-1]
+        gy2, ld2 = None, 0
+        if ctx.slot is not None and ctx.slot[0].grad is not None:
+            gy2, ld2 = _grad_rows(ctx.slot[0].grad[..., ctx.slot[1] : ctx.slot[1] + C].to(xal.dtype), C)
+        if grad_y is None:
+            if gy2 is None:
+                return (None,) * 8
+            gy, ld1, gy2, ld2 = gy2, ld2, None, 0
+        else:
+            gy, ld1 = _grad_rows(grad_y.to(xal.dtype).permute(0, 2, 3, 1), C)
+        dxa, dxb = torch.empty_like(xal), torch.empty_like(xbl)
+        plist = ctx.params
+        direct = DIRECT_WGRAD_ACCUM and all(p.requires_grad and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
+                                            for p in plist)
+        ws = zeros_f32(48 * C + (0 if direct else 4 * C), xal.device)
+        red = ws[: 48 * C]
+        if direct:
+            dga, dba, dgb, dbb = (p.grad for p in plist)
+        else:
+            dga, dba, dgb, dbb = (ws[48 * C + i * C : 48 * C + (i + 1) * C] for i in range(4))
+        es = xal.element_size()
+        n_dy = 2 if gy2 is not None else 1
+        with _lib.timed("bn_bwd_dx", ((2 + n_dy) * 2 + 2) * xal.numel() * es, f"pair {n_pix}x{C}"):
+            rc = lib.dfine_bn_pair_act_bwd(_lib.ptr(xal), _lib.ptr(xbl), _lib.ptr(gy), ld1, _lib.ptr(gy2), ld2, _lib.dtype_code(xal),
+                                           _lib.ptr(save_a), _lib.ptr(save_b), _lib.ptr(ga), _lib.ptr(ba), _lib.ptr(gb), _lib.ptr(bb),
+                                           _lib.ptr(red), _lib.ptr(dxa), _lib.ptr(dxb), _lib.ptr(dga), _lib.ptr(dba), _lib.ptr(dgb),
+                                           _lib.ptr(dbb), n_pix, C, _ACT_CODES[act], 1, eps, _lib.stream_ptr())
+        _lib.check(rc, "dfine_bn_pair_act_bwd")
+        out = (dxa.permute(0, 3, 1, 2), dxb.permute(0, 3, 1, 2))
+        if direct:
+            return out + (None,) * 6
+        # parameter gradients through autograd: hand them to the norms' parameters by hand (the modules are not tensors)
+        with torch.no_grad():
+            for p, gsrc in zip(plist, (dga, dba, dgb, dbb)):
+                if p.requires_grad:
+                    if p.grad is None:
+                        p.grad = gsrc.to(p.dtype).clone()
+                    else:
+                        p.grad.add_(gsrc.to(p.grad.dtype))  # in place: .grad may be a view of a flat gradient buffer
+        return out + (None,) * 6
+
+
+def batch_norm_pair_act_supported(xa, xb, norm_a, norm_b, ws_a, ws_b):
+    """Both branches are training-mode nn.BatchNorm2d on bf16 / fp32 CUDA maps of one shape whose batch statistics their
+    convolutions' epilogues have already accumulated (``ws_*`` from ConvNorm._conv with have_stats)."""
+    return (xa.is_cuda and xa.shape == xb.shape and xa.dtype == xb.dtype and xa.dtype in (torch.float32, torch.bfloat16)
+            and isinstance(norm_a, torch.nn.BatchNorm2d) and isinstance(norm_b, torch.nn.BatchNorm2d) and norm_a.training and norm_b.training
+            and ws_a is not None and ws_b is not None and norm_a.eps == norm_b.eps and (norm_a.momentum or 0.1) == (norm_b.momentum or 0.1)
+            and os.environ.get("DFINE_BN_PAIR", "1") != "0")
+
+
+def batch_norm_pair_act(xa, xb, norm_a, norm_b, act, ws_a, ws_b, slot=None):
+    """``act(norm_a(xa) + norm_b(xb))`` for two training-mode BatchNorm2d whose statistics are already in ``ws_a`` / ``ws_b``
+    (reference hybrid_encoder.py:115-121, VGGBlock.forward): one HIP launch forward, two backward."""
+    return _BatchNormPairAct.apply(xa, xb, norm_a, norm_b, act, ws_a, ws_b, slot)
+
+
 def bn_workspace(channels, device):
     """Zeroed workspace of one fused BatchNorm call; its first 32*C floats are the fp64 statistics replicas a producing
     conv may fill (``dense_conv(..., stats=ws[:32 * C])`` then ``batch_norm_act(..., ws=ws, have_stats=True)``)."""
@@ -836,6 +929,118 @@ def mask_logits_rows(rows, feat):
     if feat.is_cuda and feat.dim() == 4 and feat.permute(0, 2, 3, 1).is_contiguous():
         return _MaskLogits.apply(rows, feat)
     return torch.einsum("bmc,bchw->bmhw", rows, feat)
+
+
+def _grouped_wgrad_now(problems, keep, nbytes, flops):
+    """Launch a list of _lib.WgradProblem as ONE grouped launch right now (include/dfine_hip.h: dfine_wgrad_group_*),
+    outside the step's deferred queue: the results are needed by this backward pass. Under hipGraph capture the launch table
+    takes persistent memory of the installed queue (see WgradQueue); without one the problems are launched singly."""
+    lib = _lib.load()
+    n = len(problems)
+    arr = (_lib.WgradProblem * n)(*problems)
+    capturing = torch.cuda.is_current_stream_capturing()
+    need = lib.dfine_wgrad_group_plan(arr, n, None, 0) if all(lib.dfine_wgrad_group_eligible(ctypes.byref(q)) for q in problems) else 0
+    dev = None
+    if need > 0:
+        if capturing:
+            dev = wgrad_queue._persistent(int(need)) if wgrad_queue is not None else None
+        else:
+            dev = torch.empty(int(need), dtype=torch.uint8, device=keep[0].device)
+    if dev is None:
+        for q in problems:
+            _lib.check(lib.dfine_linear_wgrad(q.dY, q.X, q.dW, q.db, q.M, q.N, q.K, q.ldw, q.ldy, q.ldx, _lib.stream_ptr()), "dfine_linear_wgrad")
+        return
+    host = torch.empty(int(need), dtype=torch.uint8, pin_memory=not capturing)
+    used = lib.dfine_wgrad_group_plan(arr, n, ctypes.c_void_p(host.data_ptr()), int(need))
+    if used != need:
+        _lib.check(int(used) if used < 0 else -1, "dfine_wgrad_group_plan")
+    if capturing:
+        wgrad_queue.pending_uploads.append((dev, host))
+        wgrad_queue.max_need = max(wgrad_queue.max_need, int(need))
+    else:
+        dev.copy_(host, non_blocking=True)
+    with _lib.timed("wgrad", nbytes, f"grouped x{n} (mask rows)", flops=flops):
+        rc = lib.dfine_wgrad_group_launch(ctypes.c_void_p(host.data_ptr()), _lib.ptr(dev), _lib.stream_ptr())
+    _lib.check(rc, "dfine_wgrad_group_launch")
+    if not capturing:
+        host_keepalive.append((host, torch.cuda.current_stream().record_event()))
+        while host_keepalive and host_keepalive[0][1].query():
+            host_keepalive.pop(0)
+
+
+host_keepalive = []  # pinned launch tables whose async upload may still be in flight
+
+
+class _MaskRowsLoss(torch.autograd.Function):
+    """stats[b, n] = (sum focal terms, sum p t, sum p) of the mask logits rows[b, n] . feat[b, :, px] against ground truth
+    n % G -- the GEMM and the loss statistics in ONE kernel each way (include/dfine_hip.h: dfine_mask_rows_*): the
+    [B, N, HW] logits (680 MB at D-FINE-m 640^2 batch 32) are never written. Backward: the logits are recomputed tile by
+    tile and turned into d(loss)/d(logit) in the accumulators (bf16 [B*HW, N]), which feeds the two gradient GEMMs."""
+
+    @staticmethod
+    def forward(ctx, rows, feat, tgt, alpha):
+        lib = _lib.load()
+        B, C, H, W = feat.shape
+        N, G, HW = rows.shape[1], tgt.shape[1], H * W
+        fl = _nhwc(feat).reshape(B * HW, C)
+        r = rows.to(torch.bfloat16).contiguous()
+        t, a = tgt.float().contiguous(), alpha.float().contiguous()
+        stats = zeros_f32(B * N * 3, fl.device).view(B, N, 3)
+        with _lib.timed("mask_rows_stats", (fl.numel() + r.numel()) * 2 + t.numel() * 4, flops=2.0 * B * HW * N * C):
+            rc = lib.dfine_mask_rows_stats(_lib.ptr(fl), _lib.ptr(r), _lib.ptr(t), _lib.ptr(a), _lib.ptr(stats), B, HW, N, G, C, _lib.stream_ptr())
+        _lib.check(rc, "dfine_mask_rows_stats")
+        ctx.save_for_backward(r, fl, t, a)
+        ctx.shape = (B, C, H, W, rows.dtype)
+        return stats
+
+    @staticmethod
+    def backward(ctx, g_stats):
+        r, fl, t, a = ctx.saved_tensors
+        B, C, H, W, rows_dtype = ctx.shape
+        lib = _lib.load()
+        N, G, HW = r.shape[1], t.shape[1], H * W
+        Npad = (N + 7) // 8 * 8
+        g = g_stats.float().contiguous()
+        dz = torch.empty(B * HW, Npad, dtype=torch.bfloat16, device=fl.device)
+        if Npad != N:
+            dz[:, N:].zero_()
+        with _lib.timed("mask_rows_dz", (fl.numel() + r.numel() + dz.numel()) * 2 + t.numel() * 4, flops=2.0 * B * HW * N * C):
+            rc = lib.dfine_mask_rows_dz(_lib.ptr(fl), _lib.ptr(r), _lib.ptr(t), _lib.ptr(a), _lib.ptr(g), _lib.ptr(dz), Npad, B, HW, N, G, C,
+                                        _lib.stream_ptr())
+        _lib.check(rc, "dfine_mask_rows_dz")
+        d_rows = d_feat = None
+        if ctx.needs_input_grad[1]:
+            rows_t = torch.zeros(B, C, Npad, dtype=torch.bfloat16, device=fl.device)
+            rows_t[:, :, :N] = r.transpose(1, 2)
+            d_feat = torch.empty(B * HW, C, dtype=torch.bfloat16, device=fl.device)
+            with _lib.timed("gemm_dgrad", (dz.numel() + d_feat.numel() + rows_t.numel()) * 2, "mask d_feat", flops=2.0 * B * HW * Npad * C):
+                rc = lib.dfine_mask_rows_dfeat(_lib.ptr(dz), Npad, _lib.ptr(rows_t), Npad, _lib.ptr(d_feat), B, HW, Npad, C, _lib.stream_ptr())
+            _lib.check(rc, "dfine_mask_rows_dfeat")
+            d_feat = d_feat.view(B, H, W, C).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[0]:
+            # d_rows[b] [N, C] = dz[b]^T [N, HW] @ feat[b] [HW, C]: weight-gradient shaped (reduction over the pixel rows)
+            dr = zeros_f32(B * N * C, fl.device).view(B, N, C) if B * N * C <= (1 << 20) else torch.zeros(B, N, C, dtype=torch.float32, device=fl.device)
+            probs = [_lib.WgradProblem(dY=dz.data_ptr() + b * HW * Npad * 2, X=fl.data_ptr() + b * HW * C * 2, dW=dr.data_ptr() + b * N * C * 4,
+                                       db=None, conv=0, M=HW, N=N, K=C, ldw=C, ldy=Npad, ldx=C) for b in range(B)]
+            _grouped_wgrad_now(probs, (dz, fl, dr), (dz.numel() + fl.numel()) * 2 + dr.numel() * 4, 2.0 * B * HW * N * C)
+            d_rows = dr.to(rows_dtype)
+        return d_rows, d_feat, None, None
+
+
+def mask_rows_loss_supported(rows, feat):
+    """The fused contraction + loss statistics apply: bf16 channels_last CUDA feature map whose pixel count is a multiple of
+    the 128-row tile and whose channel count is a multiple of 8."""
+    if not (feat.is_cuda and feat.dim() == 4 and feat.dtype == torch.bfloat16 and rows.dim() == 3):
+        return False
+    B, C, H, W = feat.shape
+    return (H * W) % 128 == 0 and C % 8 == 0 and feat.permute(0, 2, 3, 1).is_contiguous() and os.environ.get("DFINE_MASK_FUSED", "1") != "0"
+
+
+def mask_rows_loss(rows, feat, tgt, alpha):
+    """rows [B, N, C], feat [B, C, H, W] channels_last bf16, tgt [B, G, H*W] in [0, 1], alpha [B, G] -> stats [B, N, 3] fp32,
+    differentiable w.r.t. rows and feat; == ``mask_row_stats(mask_logits_rows(rows, feat).flatten(2), tgt, alpha)`` without the
+    logits tensor (reference dfine_decoder.py:937-940 + dfine_criterion.py:272-357)."""
+    return _MaskRowsLoss.apply(rows, feat, tgt, alpha)
 
 
 class _BilinearAdd(torch.autograd.Function):

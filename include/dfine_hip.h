@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 17
+#define DFINE_ABI_VERSION 18
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -194,6 +194,28 @@ int dfine_bn_act_bwd(const void* x, const void* addend, const void* dy, int ld_d
                      const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
                      float* dgamma, float* dbeta, float* dlab_scale, float* dlab_bias, int n_pix, int C,
                      int act, int training, float eps, int phase, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Two training BatchNorms summed under one activation: y = act(bn_a(xa) + bn_b(xb)) -- RepVgg's training form
+ * silu(norm(conv3x3(x)) + norm(conv1x1(x))) (reference src/d_fine/arch/hybrid_encoder.py:106-121), one launch forward and
+ * two backward instead of the 4 + 4 of two dfine_bn_act_* calls chained through `addend` / `dadd` (the second branch's
+ * output and the shared dz never travel through memory).
+ *   xa, xb, y, dy, dy2, dxa, dxb: [n_pix, C] of dtype (bf16 / f32); y has pixel pitch ldy, dy / dy2 pitches ld_dy / ld_dy2
+ *   (dy2 optional: a second part of the output gradient, summed on load). sums_a / sums_b: the fp64 statistics replicas
+ *   [8][2][C] the producing convolutions' epilogues filled (dfine_igemm_bf16 `stats`); save_a / save_b f32 [2][C] receive
+ *   (mean, rstd); running statistics are updated like nn.BatchNorm2d. No LAB, no addend.
+ *   Backward: red = zeroed fp64 workspace [8][3][C]; dgamma / dbeta of both norms are ACCUMULATED (f32 [C] each).
+ * ------------------------------------------------------------------------------------- */
+int dfine_bn_pair_act_fwd(const void* xa, const void* xb, void* y, int dtype, const double* sums_a, const double* sums_b,
+                          const float* gamma_a, const float* beta_a, const float* gamma_b, const float* beta_b,
+                          float* running_mean_a, float* running_var_a, float* running_mean_b, float* running_var_b,
+                          float* save_a, float* save_b, int n_pix, int C, int act, int training, float eps, float momentum,
+                          int ldy, void* stream);
+int dfine_bn_pair_act_bwd(const void* xa, const void* xb, const void* dy, int ld_dy, const void* dy2, int ld_dy2, int dtype,
+                          const float* save_a, const float* save_b, const float* gamma_a, const float* beta_a,
+                          const float* gamma_b, const float* beta_b, double* red, void* dxa, void* dxb, float* dgamma_a,
+                          float* dbeta_a, float* dgamma_b, float* dbeta_b, int n_pix, int C, int act, int training, float eps,
+                          void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Optimizer tail over FLAT fp32 buffers of n elements (all trainable parameters, grouped).
@@ -377,6 +399,30 @@ int dfine_mask_loss_stats(const void* logits, int dtype, const float* tgt, const
                           int M, int G, int HW, void* stream);
 int dfine_mask_loss_grad(const void* logits, int dtype, const float* tgt, const float* alpha, const float* g_stats,
                          void* d_logits, int B, int M, int G, int HW, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * The mask head's contraction FUSED with that loss: logits[b][n][px] = sum_c rows[b][n][c] * feat[b][px][c]
+ * (reference src/d_fine/arch/dfine_decoder.py:937-940 `einsum('bqc,bchw->bqhw')`, consumed by
+ * src/d_fine/dfine_criterion.py:272-357) as an MFMA GEMM (csrc/igemm2.hip: pixels x rows tiles, K = C) whose epilogue
+ * reduces the row statistics above -- the [B, N, HW] logits exist only in accumulators, in either direction.
+ *   feat bf16 [B*HW, C] (the channels-last mask feature map), rows bf16 [B, N, C] (the matched queries' mask embeddings,
+ *   every head's rows concatenated; row n belongs to ground truth n % G), tgt f32 [B, G, HW], alpha f32 [B, G].
+ * dfine_mask_rows_stats: stats f32 [B, N, 3] ACCUMULATED (zero it) -- the numbers dfine_mask_loss_stats gives on the
+ *   bf16-rounded logits.
+ * dfine_mask_rows_dz: recomputes the logits and writes d(loss)/d(logit) = f(logit, t, alpha, g_stats[b][n]) as bf16
+ *   dz [B*HW, ldz >= N] (pixel-major: the operand both backward GEMMs read); columns >= N are not written.
+ * dfine_mask_rows_dfeat: d_feat [B*HW, C] bf16 = dz[b] [HW, Npad] @ rows[b] [Npad, C], given rows_t = rows[b]^T as
+ *   bf16 [B, C, ld_rt] (zero beyond N) and dz's columns N..Npad zeroed by the caller. (d_rows = dz[b]^T feat[b] is a
+ *   weight-gradient-shaped GEMM: dfine_linear_wgrad / the grouped launch.)
+ * Needs HW % 128 == 0, C % 8 == 0, Npad % 8 == 0, ldz % 8 == 0, 16-byte aligned bases; DFINE_E_UNSUPPORTED otherwise
+ * (the caller then materialises the logits: dfine_igemm_bf16 / a library GEMM + dfine_mask_loss_*).
+ * ------------------------------------------------------------------------------------- */
+int dfine_mask_rows_stats(const void* feat, const void* rows, const float* tgt, const float* alpha, float* stats, int B,
+                          int HW, int N, int G, int C, void* stream);
+int dfine_mask_rows_dz(const void* feat, const void* rows, const float* tgt, const float* alpha, const float* g_stats,
+                       void* dz, int ldz, int B, int HW, int N, int G, int C, void* stream);
+int dfine_mask_rows_dfeat(const void* dz, int ldz, const void* rows_t, int ld_rt, void* d_feat, int B, int HW, int Npad,
+                          int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Residual add + LayerNorm over the last dimension (post-norm blocks: reference

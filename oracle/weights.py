@@ -63,14 +63,46 @@ def _value(name, shape):
     return r.normal(0, 0.1, n)
 
 
-def fill_state_dict(state_dict):
-    """Returns a new dict name -> tensor with every float entry re-generated (same dtype/shape)."""
+def _value_wellcond(name, shape):
+    """A WELL-CONDITIONED variant for low-precision parity (fixtures *_wellcond): the default weights above make every conv a
+    difference of large positive terms (zero-mean filters on post-ReLU/SiLU activations), which amplifies any relative input
+    error by a few percent PER LAYER -- 60 layers on, a correct bf16 pipeline is 30-80 % from fp32 (measured on the
+    reference's own autocast and on this repo's). Here every convolution has non-negative weights that sum to
+    ~1 over the fan-in and every BatchNorm (used in eval mode) is y = gamma x + beta with beta >= 0 and unit statistics: all
+    activations stay positive and O(1), no layer cancels, and rounding errors add instead of multiplying. Linear layers
+    (followed by LayerNorm / softmax) keep the default values."""
+    r = _rng("wellcond/" + name)
+    leaf = name.rsplit(".", 1)[-1]
+    n = int(np.prod(shape)) if len(shape) else 1
+    is_norm = any(t in name for t in (".bn", ".norm", "_bn", "bn1"))
+    if leaf == "running_var":
+        return np.ones(n)
+    if leaf == "running_mean":
+        return np.zeros(n)
+    if name.endswith("lab.scale"):
+        return r.uniform(0.8, 1.2, n)
+    if name.endswith("lab.bias"):
+        return r.uniform(0.0, 0.1, n)
+    if is_norm and leaf == "weight" and len(shape) == 1:
+        return r.uniform(0.8, 1.2, n)
+    if is_norm and leaf == "bias" and len(shape) == 1:
+        return r.uniform(0.0, 0.1, n)
+    if len(shape) == 4:
+        fan_in = shape[0] if "upconv" in name else int(np.prod(shape[1:]))  # ConvTranspose2d [in, out, 2, 2]: one tap per input channel
+        return np.abs(r.normal(0, 1.0, n)).reshape(shape) / (0.798 * fan_in)
+    return _value(name, shape)
+
+
+def fill_state_dict(state_dict, conditioning="default"):
+    """Returns a new dict name -> tensor with every float entry re-generated (same dtype/shape). ``conditioning="wellcond"``:
+    see _value_wellcond."""
     out = {}
+    gen = _value if conditioning == "default" else _value_wellcond
     for name, t in state_dict.items():
         if (not t.dtype.is_floating_point) or name in KEEP_NAMES or name.endswith(KEEP_SUFFIXES):
             out[name] = t.detach().clone()
             continue
-        v = np.asarray(_value(name, tuple(t.shape)), dtype=np.float64).reshape(tuple(t.shape))
+        v = np.asarray(gen(name, tuple(t.shape)), dtype=np.float64).reshape(tuple(t.shape))
         out[name] = torch.from_numpy(v.astype(np.float32)).to(t.dtype)
     return out
 

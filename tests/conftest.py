@@ -30,3 +30,19 @@ def hip_lib():
     from dfine_seg_amd import _lib
 
     return _lib.load()
+
+
+@pytest.fixture(autouse=True)
+def _reset_step_scoped_handles():
+    """``ops.wgrad_queue`` / ``ops.zero_arena`` are module-level handles a TrainStep installs for the duration of its step;
+    a test that runs only part of a step (forward + backward, no optimizer tail) must not leak them into the next test,
+    whose weight gradients would be parked in a queue nobody flushes."""
+    yield
+    import sys
+
+    ops = sys.modules.get("dfine_seg_amd.ops")
+    if ops is not None:
+        if getattr(ops, "wgrad_queue", None) is not None:
+            ops.wgrad_queue.discard()
+        ops.wgrad_queue = None
+        ops.zero_arena = None

@@ -118,3 +118,63 @@ def test_running_statistics_backward(hip_lib, frozen, act, with_add):
     if not frozen:
         torch.testing.assert_close(gd.grad.cpu(), gr.grad, rtol=1e-3, atol=1e-3)
         torch.testing.assert_close(bd.grad.cpu(), br.grad, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 128, 40, 40), (3, 64, 9, 7), (2, 24, 16, 16), (1, 21, 10, 10)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_pair_act_matches_torch_fp32(hip_lib, B, C, H, W, dtype):
+    """y = silu(bn_a(xa) + bn_b(xb)) in one launch (dfine_bn_pair_act_*, RepVgg's training form, hybrid_encoder.py:115-121)
+    against F.batch_norm x 2 + silu in fp32: output, both input gradients, the four parameter gradients and the running
+    statistics of both norms. The batch statistics arrive the way the model delivers them: in the workspaces the
+    convolutions' epilogues fill (here filled by the standalone statistics pass)."""
+    import torch.nn as nn
+
+    from dfine_seg_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(C * 3 + H)
+    xa = (torch.randn(B, C, H, W, generator=g) * 0.5 + 2.0).to(dtype)
+    xb = (torch.randn(B, C, H, W, generator=g) * 1.5 - 1.0).to(dtype)
+    gy = torch.randn(B, C, H, W, generator=g).to(dtype)
+    norms_ref, norms = [], []
+    for i in range(2):
+        n = nn.BatchNorm2d(C)
+        with torch.no_grad():
+            n.weight.copy_(torch.rand(C, generator=g) + 0.5)
+            n.bias.copy_(torch.randn(C, generator=g) * 0.1)
+            n.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+            n.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+        import copy
+        norms_ref.append(n.train())
+        norms.append(copy.deepcopy(n).cuda().train())
+    xar, xbr = xa.float().clone().requires_grad_(True), xb.float().clone().requires_grad_(True)
+    y_ref = F.silu(norms_ref[0](xar) + norms_ref[1](xbr))
+    y_ref.backward(gy.float())
+
+    cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xad, xbd = cl(xa), cl(xb)
+    ws = []
+    for x in (xad, xbd):  # batch statistics into the norm workspaces, as a conv epilogue would leave them
+        w = torch.zeros(34 * C, device="cuda")
+        xl = x.detach().permute(0, 2, 3, 1).contiguous()
+        dummy = torch.empty_like(xl)
+        ones, zeros = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+        rc = hip_lib.dfine_bn_act_fwd(_lib.ptr(xl), None, _lib.ptr(dummy), _lib.dtype_code(xl), _lib.ptr(w), _lib.ptr(ones), _lib.ptr(zeros),
+                                      _lib.ptr(zeros.clone()), _lib.ptr(ones.clone()), _lib.ptr(w[32 * C:]), _lib.ptr(w[33 * C:]), None, None,
+                                      B * H * W, C, 0, 1, 1e-5, 0.1, 1, 0, None, 0, _lib.stream_ptr())
+        assert rc == 0
+        ws.append(w)
+    assert ops.batch_norm_pair_act_supported(xad, xbd, norms[0], norms[1], ws[0], ws[1])
+    y = ops.batch_norm_pair_act(xad, xbd, norms[0], norms[1], "silu", ws[0], ws[1])
+    assert y.dtype == dtype and y.shape == y_ref.shape
+    y.backward(gy.cuda())
+    torch.cuda.synchronize()
+    tol = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(y.float().cpu(), y_ref.detach(), **tol)
+    torch.testing.assert_close(xad.grad.float().cpu(), xar.grad, **tol)
+    torch.testing.assert_close(xbd.grad.float().cpu(), xbr.grad, **tol)
+    ptol = dict(rtol=2e-3, atol=2e-3 * (B * H * W) ** 0.5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2 * (B * H * W) ** 0.5)
+    for n, nr in zip(norms, norms_ref):
+        torch.testing.assert_close(n.weight.grad.cpu(), nr.weight.grad, **ptol)
+        torch.testing.assert_close(n.bias.grad.cpu(), nr.bias.grad, **ptol)
+        torch.testing.assert_close(n.running_mean.cpu(), nr.running_mean, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(n.running_var.cpu(), nr.running_var, rtol=1e-3, atol=1e-5)

@@ -367,3 +367,78 @@ def test_flat_allreduce_between_captured_graphs_rccl_single_rank(hip_lib):
     proc = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
     err = "\n".join(l for l in proc.stderr.splitlines() if not l.startswith("frame #"))
     assert proc.returncode == 0 and "RCCL_GRAPH_OK" in proc.stdout, proc.stdout[-2000:] + err[-6000:]
+
+
+_RCCL_GRAPH_AMP_SCRIPT = """
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import dfine_seg_amd
+from dfine_seg_amd.ddp import FlatGradAllReduce, StagedGradAllReduce
+from dfine_seg_amd.synth import synthetic_batch
+from dfine_seg_amd.train import TrainStep, _SplitGraph, _StagedGraph
+from test_optim import _snapshot, _restore
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT={port!r}, RANK="0", WORLD_SIZE="1")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+batches = [synthetic_batch(2, 320, 320, 80, n, seed=1 + n, device="cuda") for n in (4, 6)]  # two GT-count keys = two graphs
+rel = lambda a, b: float((a - b).norm() / b.norm())
+for reducer in (None, FlatGradAllReduce, StagedGradAllReduce):
+    name = getattr(reducer, "__name__", "unsplit")
+    torch.manual_seed(0)
+    trainer = TrainStep("n", 80, False, (320, 320), "cuda", grad_reducer=reducer, total_steps=100, graph_warmup=1, amp=True)
+    # the flat gradient as the optimizer finds it: a copy made at the head of the optimizer tail (captured with it)
+    snap_g = torch.zeros_like(trainer.flat.grads)
+    launch = trainer.optimizer.launch
+    def snapshotting_launch(snap_g=snap_g, launch=launch, flat=trainer.flat):
+        snap_g.copy_(flat.grads)
+        launch()
+    trainer.optimizer.launch = snapshotting_launch
+    torch.manual_seed(5)
+    trainer.step(*batches[0])  # the eager warm-up step (moves the weights off their initial values)
+    for key, batch in enumerate(batches):
+        state = _snapshot(trainer)
+        runs = []
+        for mode in ("eager", "capture+replay", "replay", "replay"):  # all FROM THE SAME STATE: only atomic order differs
+            _restore(trainer, state)
+            trainer.use_graph = mode != "eager"
+            torch.manual_seed(200 + key)
+            loss = float(trainer.step(*batch))
+            assert trainer.last_step_replayed == (mode != "eager"), (name, mode)
+            runs.append((loss, snap_g.clone(), trainer.flat.params.clone()))
+        for mode, (loss, grad, params) in zip(("capture+replay", "replay", "replay"), runs[1:]):
+            cos = float(torch.dot(grad, runs[0][1]) / (grad.norm() * runs[0][1].norm()))
+            print(name, "key", key, mode, "loss", loss, "vs eager", runs[0][0], "gradient cosine", round(cos, 5), "norm ratio",
+                  round(float(grad.norm() / runs[0][1].norm()), 4), "params rel", rel(params, runs[0][2]), file=sys.stderr)
+            assert abs(loss - runs[0][0]) <= 1e-2 * abs(runs[0][0]), (name, key, mode, loss, runs[0][0])
+            assert cos > 0.995 and abs(float(grad.norm() / runs[0][1].norm()) - 1) < 0.03, (name, key, mode, cos)
+            assert rel(params, runs[0][2]) < 3e-3, (name, key, mode)
+    assert len(trainer._graphs) == 2
+    kind = {{None: torch.cuda.CUDAGraph, FlatGradAllReduce: _SplitGraph, StagedGradAllReduce: _StagedGraph}}[reducer]
+    assert all(isinstance(e[0], kind) for e in trainer._graphs.values())
+    assert trainer.wgrad_queue.launches > 0 and trainer.wgrad_queue.single_fallbacks == 0, (trainer.wgrad_queue.launches, trainer.wgrad_queue.single_fallbacks)
+    assert float(trainer.flat.grads.abs().max()) == 0.0
+    del trainer, launch, snapshotting_launch
+    import gc; gc.collect(); torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL_GRAPH_AMP_OK")
+"""
+
+
+@pytest.mark.gpu
+def test_staged_and_flat_graph_schedules_bf16_rccl_single_rank(hip_lib):
+    """The N>1 schedules in the precision that is benchmarked (amp=True: implicit-GEMM kernels, ConcatBuffer gradients parked
+    across the detach cuts, WgradQueue.flush() per captured stage with persistent launch tables, bf16 leaf gradients chained by
+    _backward_through) on a 1-rank RCCL group. For the unsplit graph, the flat and the staged schedule, and for TWO
+    ground-truth-count keys each: the step run eagerly and its capture + 3 replays all start FROM THE SAME STATE (weights,
+    moments, EMA, BatchNorm statistics, counters, RNG), so they differ only by float-atomic order -- loss within 1e-2, the flat
+    gradient the optimizer graph receives at cosine > 0.995 and norm within 3 %, updated weights within 3e-3. Every weight
+    gradient goes through the grouped launch (no single-launch fallback)."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    script = _RCCL_GRAPH_AMP_SCRIPT.format(root=ROOT, port=str(_free_port()))
+    proc = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=900)
+    err = "\n".join(l for l in proc.stderr.splitlines() if not l.startswith("frame #"))
+    assert proc.returncode == 0 and "RCCL_GRAPH_AMP_OK" in proc.stdout, proc.stdout[-2000:] + err[-6000:]

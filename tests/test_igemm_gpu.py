@@ -13,6 +13,17 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["auto", "register-staged", "lds-dma-ring"])
+def igemm_body(request, monkeypatch):
+    """Every case runs through the dispatcher's own choice and through each of the two kernel bodies forced for all
+    launches (csrc/igemm.hip register-staged, csrc/igemm2.hip LDS-DMA ring; DFINE_IGEMM_V is read per call)."""
+    if request.param != "auto":
+        monkeypatch.setenv("DFINE_IGEMM_V", "1" if request.param == "register-staged" else "2")
+    else:
+        monkeypatch.delenv("DFINE_IGEMM_V", raising=False)
+    return request.param
+
+
 def _bf(t):
     return t.to(torch.bfloat16)
 
