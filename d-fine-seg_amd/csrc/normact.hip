@@ -33,21 +33,34 @@ struct NaGeom {
   int ldy;            // forward: pixel pitch of the OUTPUT (>= C: a channel slice of a concat buffer)
   int ld_post;        // forward: pixel pitch of the optional residual added AFTER activation and LAB
   int ld_dy, ld_dy2;  // backward: pixel pitches of the output gradient and of its optional second part (dy + dy2)
+  int dbg;            // diagnostics (tools/bench_bn.py, DFINE_BN_DEBUG): 1 = skip the global atomics of the column reduction,
+                      // 2 = skip the column reduction altogether
 };
 
+// sigmoid through v_exp + v_rcp (1 ulp; an IEEE division is a ~10-instruction sequence per element, and these kernels are
+// bound by instruction issue, not by HBM: profiles/r03_bn_kernels.txt)
+__device__ __forceinline__ float fast_sigmoid(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
 __device__ __forceinline__ float act_fwd(float z, int act) {
   if (act == ACT_RELU) return fmaxf(z, 0.f);
-  if (act == ACT_SILU) return z / (1.f + __expf(-z));
+  if (act == ACT_SILU) return z * fast_sigmoid(z);
   return z;
 }
 __device__ __forceinline__ float act_grad(float z, int act) {
   if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;
   if (act == ACT_SILU) {
-    const float s = 1.f / (1.f + __expf(-z));
+    const float s = fast_sigmoid(z);
     return s * (1.f + z * (1.f - s));
   }
   return 1.f;
 }
+// Compile-time specialisation of the streaming kernels: FLAGS >= 0 fixes (bit 0 addend, bit 1 second gradient part / POST
+// residual, bit 2 LAB, bits 3-4 activation) so the per-element code has no branch and no dead transcendental; FLAGS < 0
+// reads them at run time (the rarely used vector widths: compile time).
+#define NA_OPTS(FLAGS, g, second_ptr)                                              \
+  const bool ADD = (FLAGS) < 0 ? (g).has_add != 0 : (((FLAGS)&1) != 0);            \
+  const bool SEC = (FLAGS) < 0 ? (second_ptr) != nullptr : (((FLAGS)&2) != 0);     \
+  const bool LAB = (FLAGS) < 0 ? (g).has_lab != 0 : (((FLAGS)&4) != 0);            \
+  const int ACTV = (FLAGS) < 0 ? (g).act : (((FLAGS) >> 3) & 3);
 
 // blockDim = (channel groups of VEC, pixel rows). Thread (cx, py) owns channels
 // [ (blockIdx.y*blockDim.x + cx)*VEC, +VEC ) and pixels blockIdx.x*blockDim.y*ppt + py + n*blockDim.y.
@@ -56,7 +69,11 @@ struct ColReduce {
   // Sum NQ quantities x VEC channels over the block's pixel rows through LDS, then one fp64 atomic
   // per (quantity, channel) per block into out[q*C + c].
   template <int VEC>
-  __device__ static __forceinline__ void run(float (&acc)[NQ][VEC], float* red, double* out, int C, int c0) {
+  __device__ static __forceinline__ void run(float (&acc)[NQ][VEC], float* red, double* out, int C, int c0, int dbg = 0) {
+    if (dbg & 2) {
+      if (acc[0][0] == 12345.678f) out[0] = 1.0;  // keeps the accumulation alive
+      return;
+    }
     const int lanes = blockDim.x * VEC;  // channels covered by the block
     float* mine = red + (size_t)threadIdx.y * NQ * lanes + threadIdx.x * VEC;
 #pragma unroll
@@ -69,6 +86,10 @@ struct ColReduce {
       float s = 0.f;
       for (int r = 0; r < (int)blockDim.y; ++r) s += red[(size_t)r * NQ * lanes + e];
       const int q = e / lanes, c = e - q * lanes;
+      if (dbg & 1) {
+        if (s == 12345.678f) out[0] = 1.0;
+        continue;
+      }
       atomicAdd(out + ((size_t)(blockIdx.x % NA_REPLICAS) * NQ + q) * C + (c0 - threadIdx.x * VEC) + c, (double)s);
     }
   }
@@ -113,7 +134,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 
 // Forward apply. One thread per channel of the block's slice turns the fp64 sums (training) or the
 // running statistics (eval) into scale/shift in LDS; block row 0 also keeps the books.
-template <typename T, int VEC, bool POST>
+template <typename T, int VEC, int FLAGS>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const T* __restrict__ x, const T* __restrict__ addend, const T* __restrict__ post, T* __restrict__ y,
     const double* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -162,10 +183,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     scale[i] = cst[threadIdx.x * VEC + i];
     shift[i] = cst[lanes + threadIdx.x * VEC + i];
   }
-  const float ls = g.has_lab ? lab_scale[0] : 1.f, lb = g.has_lab ? lab_bias[0] : 0.f;
+  NA_OPTS(FLAGS, g, post)
+  const bool POST = SEC;
+  const float ls = LAB ? lab_scale[0] : 1.f, lb = LAB ? lab_bias[0] : 0.f;
   const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
   for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL) {
-    float v[DFINE_NA_UNROLL][VEC], a[DFINE_NA_UNROLL][VEC], r[POST ? DFINE_NA_UNROLL : 1][VEC];
+    float v[DFINE_NA_UNROLL][VEC], a[DFINE_NA_UNROLL][VEC], r[DFINE_NA_UNROLL][VEC];
     bool ok[DFINE_NA_UNROLL];
 #pragma unroll
     for (int u = 0; u < DFINE_NA_UNROLL; ++u) {
@@ -174,8 +197,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
       if (ok[u]) {
         const size_t off = (size_t)pix * g.C + c0;
         load_vec<T, VEC>(x + off, v[u]);
-        if (g.has_add) load_vec<T, VEC>(addend + off, a[u]);
-        if (POST) load_vec<T, VEC>(post + (size_t)pix * g.ld_post + c0, r[POST ? u : 0]);
+        if (ADD) load_vec<T, VEC>(addend + off, a[u]);
+        if (POST) load_vec<T, VEC>(post + (size_t)pix * g.ld_post + c0, r[u]);
       }
     }
 #pragma unroll
@@ -184,9 +207,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         float z = v[u][i] * scale[i] + shift[i];
-        if (g.has_add) z += a[u][i];
-        v[u][i] = ls * act_fwd(z, g.act) + lb;
-        if (POST) v[u][i] += r[POST ? u : 0][i];  // the block's residual: out = lab(act(norm(x))) + residual, one rounding
+        if (ADD) z += a[u][i];
+        v[u][i] = ls * act_fwd(z, ACTV) + lb;
+        if (POST) v[u][i] += r[u][i];  // the block's residual: out = lab(act(norm(x))) + residual, one rounding
       }
       store_vec<T, VEC>(y + (size_t)(first + (n + u) * blockDim.y) * g.ldy + c0, v[u]);
     }
@@ -194,7 +217,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
 }
 
 // Backward pass 1: per channel sum(dz), sum(dz * xhat), sum(dy * act(z)) [-> d lab_scale], sum(dy) [-> d lab_bias]
-template <typename T, int VEC, int UNROLL>
+template <typename T, int VEC, int UNROLL, int FLAGS>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const T* __restrict__ x, const T* __restrict__ addend, const T* __restrict__ dy, const T* __restrict__ dy2,
     const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
@@ -223,7 +246,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     bet[i] = red[3 * lanes + k];
   }
   __syncthreads();  // `red` is reused by the column reduction below
-  const float ls = g.has_lab ? lab_scale[0] : 1.f;
+  NA_OPTS(FLAGS, g, dy2)
+  const bool DY2 = SEC;
+  const float ls = LAB ? lab_scale[0] : 1.f;
   float acc[4][VEC];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -241,8 +266,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         const size_t off = (size_t)pix * g.C + c0;
         px[u].load(x + off);
         pd[u].load(dy + (size_t)pix * g.ld_dy + c0);
-        if (dy2) pe[u].load(dy2 + (size_t)pix * g.ld_dy2 + c0);
-        if (g.has_add) pa[u].load(addend + off);
+        if (DY2) pe[u].load(dy2 + (size_t)pix * g.ld_dy2 + c0);
+        if (ADD) pa[u].load(addend + off);
       }
     }
 #pragma unroll
@@ -251,34 +276,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
       float v[VEC], a[VEC], d[VEC];
       px[u].unpack(v);
       pd[u].unpack(d);
-      if (dy2) {  // the output feeds two consumers (next layer + a concat slice): their gradients are summed on load
+      if (DY2) {  // the output feeds two consumers (next layer + a concat slice): their gradients are summed on load
         float d2[VEC];
         pe[u].unpack(d2);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) d[i] += d2[i];
       }
-      if (g.has_add) pa[u].unpack(a);
+      if (ADD) pa[u].unpack(a);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float xhat = (v[i] - mean[i]) * rstd[i];
         float z = xhat * gam[i] + bet[i];
-        if (g.has_add) z += a[i];
-        const float dz = d[i] * ls * act_grad(z, g.act);
+        if (ADD) z += a[i];
+        const float dz = d[i] * ls * act_grad(z, ACTV);
         acc[0][i] += dz;
         acc[1][i] += dz * xhat;
-        if (g.has_lab) {  // d lab_scale / d lab_bias only; without LAB this saves SiLU's second exponential
-          acc[2][i] += d[i] * act_fwd(z, g.act);
+        if (LAB) {  // d lab_scale / d lab_bias only; without LAB this saves SiLU's second exponential
+          acc[2][i] += d[i] * act_fwd(z, ACTV);
           acc[3][i] += d[i];
         }
       }
     }
   }
-  ColReduce<T, 4>::template run<VEC>(acc, red, red_out, g.C, c0);
+  ColReduce<T, 4>::template run<VEC>(acc, red, red_out, g.C, c0, g.dbg);
 }
 
 // Backward pass 2: dx = gamma*rstd * (dz - mean(dz) - xhat*mean(dz*xhat)); dadd = dz;
 // block row 0 also publishes dgamma/dbeta (fp32) and adds its channels' share of d lab.
-template <typename T, int VEC>
+template <typename T, int VEC, int FLAGS>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
     const T* __restrict__ x, const T* __restrict__ addend, const T* __restrict__ dy, const T* __restrict__ dy2,
     const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
@@ -290,6 +315,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
   const int lanes = blockDim.x * VEC;
   const int cbase = blockIdx.y * lanes;
   const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  NA_OPTS(FLAGS, g, dy2)
+  const bool DY2 = SEC;
   const float inv_n = 1.f / (float)g.n_pix;
   // d lab_scale / d lab_bias are sums over ALL channels: the channels of this block are added up in LDS first (the global
   // adds of a 128..1536-channel map all hit the same two floats and would serialise behind workgroup 0 otherwise)
@@ -314,14 +341,14 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
     if (blockIdx.x == 0) {  // one writer per channel: accumulate (the caller may point these at .grad)
       dgamma[c] += s_dzx;
       dbeta[c] += s_dz;
-      if (g.has_lab) {
+      if (LAB) {
         atomicAdd(&lab_part[0], (float)r2);
         atomicAdd(&lab_part[1], (float)r3);
       }
     }
   }
   __syncthreads();
-  if (blockIdx.x == 0 && g.has_lab && tid < 2) atomicAdd(tid == 0 ? dlab_scale : dlab_bias, lab_part[tid]);
+  if (blockIdx.x == 0 && LAB && tid < 2) atomicAdd(tid == 0 ? dlab_scale : dlab_bias, lab_part[tid]);
   const int c0 = cbase + threadIdx.x * VEC;
   float mean[VEC], rstd[VEC], gam[VEC], bet[VEC], m_dz[VEC], m_dzx[VEC];
 #pragma unroll
@@ -334,7 +361,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
     m_dz[i] = cst[4 * lanes + k];
     m_dzx[i] = cst[5 * lanes + k];
   }
-  const float ls = g.has_lab ? lab_scale[0] : 1.f;
+  const float ls = LAB ? lab_scale[0] : 1.f;
   const int first = blockIdx.x * blockDim.y * g.pix_per_thread + threadIdx.y;
   for (int n = 0; n < g.pix_per_thread; n += DFINE_NA_UNROLL_BWD) {
     PackedVec<T, VEC> px[DFINE_NA_UNROLL_BWD], pa[DFINE_NA_UNROLL_BWD], pd[DFINE_NA_UNROLL_BWD], pe[DFINE_NA_UNROLL_BWD];
@@ -347,8 +374,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
         const size_t off = (size_t)pix * g.C + c0;
         px[u].load(x + off);
         pd[u].load(dy + (size_t)pix * g.ld_dy + c0);
-        if (dy2) pe[u].load(dy2 + (size_t)pix * g.ld_dy2 + c0);
-        if (g.has_add) pa[u].load(addend + off);
+        if (DY2) pe[u].load(dy2 + (size_t)pix * g.ld_dy2 + c0);
+        if (ADD) pa[u].load(addend + off);
       }
     }
 #pragma unroll
@@ -358,24 +385,24 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
       float v[VEC], a[VEC], d[VEC];
       px[u].unpack(v);
       pd[u].unpack(d);
-      if (dy2) {
+      if (DY2) {
         float d2[VEC];
         pe[u].unpack(d2);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) d[i] += d2[i];
       }
-      if (g.has_add) pa[u].unpack(a);
+      if (ADD) pa[u].unpack(a);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float xhat = (v[i] - mean[i]) * rstd[i];
         float z = xhat * gam[i] + bet[i];
-        if (g.has_add) z += a[i];
-        const float dz = d[i] * ls * act_grad(z, g.act);
+        if (ADD) z += a[i];
+        const float dz = d[i] * ls * act_grad(z, ACTV);
         a[i] = dz;
         v[i] = gam[i] * rstd[i] * (dz - m_dz[i] - xhat * m_dzx[i]);
       }
       store_vec<T, VEC>(dx + off, v);
-      if (g.has_add) store_vec<T, VEC>(dadd + off, a);
+      if (ADD) store_vec<T, VEC>(dadd + off, a);
     }
   }
 }
@@ -388,7 +415,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(
 // memory as `dadd`: 4 + 4 launches and 13 map passes backward. Here: 1 launch forward (xa, xb -> y), 2 backward
 // (reduce: xa, xb, dy -> 3 sums per channel; dx: xa, xb, dy -> dxa, dxb), 8 passes.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int VEC>
+template <typename T, int VEC, int ACT>
 __global__ __launch_bounds__(256) void bn_pair_apply_kernel(
     const T* __restrict__ xa, const T* __restrict__ xb, T* __restrict__ y, const double* __restrict__ sums_a,
     const double* __restrict__ sums_b, const float* __restrict__ gamma_a, const float* __restrict__ beta_a,
@@ -468,14 +495,14 @@ __global__ __launch_bounds__(256) void bn_pair_apply_kernel(
       pa[u].unpack(va);
       pb[u].unpack(vb);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) va[i] = act_fwd(va[i] * sa[i] + vb[i] * sb[i] + sh[i], g.act);
+      for (int i = 0; i < VEC; ++i) va[i] = act_fwd(va[i] * sa[i] + vb[i] * sb[i] + sh[i], ACT < 0 ? g.act : ACT);
       store_vec<T, VEC>(y + (size_t)(first + (n + u) * blockDim.y) * g.ldy + c0, va);
     }
   }
 }
 
 // backward pass 1 of the pair: per channel sum(dz), sum(dz * xhat_a), sum(dz * xhat_b)
-template <typename T, int VEC>
+template <typename T, int VEC, int ACT>
 __global__ __launch_bounds__(256) void bn_pair_bwd_reduce_kernel(
     const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ dy, const T* __restrict__ dy2,
     const float* __restrict__ save_a, const float* __restrict__ save_b, const float* __restrict__ gamma_a,
@@ -541,7 +568,7 @@ __global__ __launch_bounds__(256) void bn_pair_bwd_reduce_kernel(
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float ha = (va[i] - mean_a[i]) * rstd_a[i], hb = (vb[i] - mean_b[i]) * rstd_b[i];
-        const float dz = d[i] * act_grad(ha * gam_a[i] + hb * gam_b[i] + bet[i], g.act);
+        const float dz = d[i] * act_grad(ha * gam_a[i] + hb * gam_b[i] + bet[i], ACT < 0 ? g.act : ACT);
         acc[0][i] += dz;
         acc[1][i] += dz * ha;
         acc[2][i] += dz * hb;
@@ -552,7 +579,7 @@ __global__ __launch_bounds__(256) void bn_pair_bwd_reduce_kernel(
 }
 
 // backward pass 2 of the pair: dxa, dxb; block row 0 publishes dgamma / dbeta of both norms
-template <typename T, int VEC>
+template <typename T, int VEC, int ACT>
 __global__ __launch_bounds__(256) void bn_pair_bwd_dx_kernel(
     const T* __restrict__ xa, const T* __restrict__ xb, const T* __restrict__ dy, const T* __restrict__ dy2,
     const float* __restrict__ save_a, const float* __restrict__ save_b, const float* __restrict__ gamma_a,
@@ -631,7 +658,7 @@ __global__ __launch_bounds__(256) void bn_pair_bwd_dx_kernel(
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
         const float ha = (va[i] - mean_a[i]) * rstd_a[i], hb = (vb[i] - mean_b[i]) * rstd_b[i];
-        const float dz = d[i] * act_grad(ha * gam_a[i] + hb * gam_b[i] + bet[i], g.act);
+        const float dz = d[i] * act_grad(ha * gam_a[i] + hb * gam_b[i] + bet[i], ACT < 0 ? g.act : ACT);
         va[i] = gam_a[i] * rstd_a[i] * (dz - m_dz[i] - ha * m_a[i]);
         vb[i] = gam_b[i] * rstd_b[i] * (dz - m_dz[i] - hb * m_b[i]);
       }
@@ -652,6 +679,22 @@ static int reduce_target_blocks() {
   const int v = e ? atoi(e) : 512;
   return v < 64 ? 64 : v;
 }
+
+// 24 specialisations (8 flag combinations x 3 activations) for the 16-byte bf16 vector that carries the model's maps; the
+// narrow vectors (channel counts that are not multiples of 8) and fp32 (parity runs) share one run-time-flag instantiation
+// each (a code object with ~600 kernels failed to resolve its later symbols at launch: keep the count moderate)
+#define NA_CASE(L, F) case F: L(F); break;
+#define NA_FLAG_SWITCH(flags, L)                                                                                       \
+  if constexpr (sizeof(T) == 2 && VEC == 8) {                                                                          \
+    switch (flags) {                                                                                                   \
+      NA_CASE(L, 0) NA_CASE(L, 1) NA_CASE(L, 2) NA_CASE(L, 3) NA_CASE(L, 4) NA_CASE(L, 5) NA_CASE(L, 6) NA_CASE(L, 7)    \
+      NA_CASE(L, 8) NA_CASE(L, 9) NA_CASE(L, 10) NA_CASE(L, 11) NA_CASE(L, 12) NA_CASE(L, 13) NA_CASE(L, 14) NA_CASE(L, 15) \
+      NA_CASE(L, 16) NA_CASE(L, 17) NA_CASE(L, 18) NA_CASE(L, 19) NA_CASE(L, 20) NA_CASE(L, 21) NA_CASE(L, 22)           \
+      default: L(23); break;                                                                                           \
+    }                                                                                                                  \
+  } else {                                                                                                             \
+    L(-1);                                                                                                             \
+  }
 
 struct NaLaunch {
   dim3 grid, block;
@@ -681,6 +724,8 @@ static NaGeom make_geom(int n_pix, int C, int ppt, int act, bool has_add, bool h
   g.n_pix = n_pix; g.C = C; g.pix_per_thread = ppt; g.act = act; g.has_add = has_add; g.has_lab = has_lab;
   g.training = training; g.eps = eps; g.momentum = momentum;
   g.ldy = g.ld_dy = g.ld_dy2 = g.ld_post = C;
+  const char* e = getenv("DFINE_BN_DEBUG");
+  g.dbg = e ? atoi(e) : 0;
   return g;
 }
 
@@ -702,12 +747,13 @@ static int fwd_impl(const void* x, const void* addend, void* y, double* sums, co
   NaGeom g = make_geom(n_pix, C, A.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, momentum);
   g.ldy = ldy;
   g.ld_post = ld_post;
-  if (post)
-    hipLaunchKernelGGL((bn_apply_kernel<T, VEC, true>), A.grid, A.block, (size_t)2 * A.block.x * VEC * sizeof(float), st, (const T*)x, (const T*)addend, (const T*)post, (T*)y, sums, gamma, beta,
-                       running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, g);
-  else
-    hipLaunchKernelGGL((bn_apply_kernel<T, VEC, false>), A.grid, A.block, (size_t)2 * A.block.x * VEC * sizeof(float), st, (const T*)x, (const T*)addend, (const T*)post, (T*)y, sums, gamma, beta,
-                       running_mean, running_var, save_mean, save_rstd, lab_scale, lab_bias, g);
+  const int flags = (addend ? 1 : 0) | (post ? 2 : 0) | (lab_scale ? 4 : 0) | (act << 3);
+#define APPLY_LAUNCH(F)                                                                                                              \
+  hipLaunchKernelGGL((bn_apply_kernel<T, VEC, F>), A.grid, A.block, (size_t)2 * A.block.x * VEC * sizeof(float), st, (const T*)x,     \
+                     (const T*)addend, (const T*)post, (T*)y, sums, gamma, beta, running_mean, running_var, save_mean, save_rstd,      \
+                     lab_scale, lab_bias, g)
+  NA_FLAG_SWITCH(flags, APPLY_LAUNCH)
+#undef APPLY_LAUNCH
   DFINE_LAUNCH_CHECK();
   return 0;
 }
@@ -722,24 +768,24 @@ static int bwd_impl(const void* x, const void* addend, const void* dy, int ld_dy
   if (int rc = plan<VEC>(&A, n_pix, C, apply_target_blocks())) return rc;
   NaGeom g = make_geom(n_pix, C, R.ppt, act, addend != nullptr, lab_scale != nullptr, training, eps, 0.f);
   g.ld_dy = ld_dy, g.ld_dy2 = ld_dy2;
+  const int flags = (addend ? 1 : 0) | (dy2 ? 2 : 0) | (lab_scale ? 4 : 0) | (act << 3);
   if (phase != 2) {
     const size_t lds = (size_t)R.block.y * 4 * R.block.x * VEC * sizeof(float);
-    const int unroll = getenv("DFINE_BN_BWD_UNROLL") ? atoi(getenv("DFINE_BN_BWD_UNROLL")) : 2;
-    if (unroll == 8)
-      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, 8>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy, (const T*)dy2,
-                         save_mean, save_rstd, gamma, beta, lab_scale, red, g);
-    else if (unroll == 4)
-      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, 4>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy, (const T*)dy2,
-                         save_mean, save_rstd, gamma, beta, lab_scale, red, g);
-    else
-      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, 2>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy, (const T*)dy2,
-                         save_mean, save_rstd, gamma, beta, lab_scale, red, g);
+#define RED_LAUNCH(F)                                                                                                            \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, VEC, 2, F>), R.grid, R.block, lds, st, (const T*)x, (const T*)addend, (const T*)dy, \
+                     (const T*)dy2, save_mean, save_rstd, gamma, beta, lab_scale, red, g)
+    NA_FLAG_SWITCH(flags, RED_LAUNCH)
+#undef RED_LAUNCH
     DFINE_LAUNCH_CHECK();
   }
   if (phase == 1) return 0;
   g.pix_per_thread = A.ppt;
-  hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VEC>), A.grid, A.block, (size_t)6 * A.block.x * VEC * sizeof(float), st, (const T*)x, (const T*)addend, (const T*)dy, (const T*)dy2, save_mean,
-                     save_rstd, gamma, beta, lab_scale, red, (T*)dx, (T*)dadd, dgamma, dbeta, dlab_scale, dlab_bias, g);
+#define DX_LAUNCH(F)                                                                                                                  \
+  hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VEC, F>), A.grid, A.block, (size_t)6 * A.block.x * VEC * sizeof(float), st, (const T*)x,     \
+                     (const T*)addend, (const T*)dy, (const T*)dy2, save_mean, save_rstd, gamma, beta, lab_scale, red, (T*)dx, (T*)dadd, \
+                     dgamma, dbeta, dlab_scale, dlab_bias, g)
+  NA_FLAG_SWITCH(flags, DX_LAUNCH)
+#undef DX_LAUNCH
   DFINE_LAUNCH_CHECK();
   return 0;
 }
@@ -753,8 +799,11 @@ static int pair_fwd_impl(const void* xa, const void* xb, void* y, const double* 
   if (int rc = plan<VEC>(&A, n_pix, C, apply_target_blocks())) return rc;
   NaGeom g = make_geom(n_pix, C, A.ppt, act, false, false, training, eps, momentum);
   g.ldy = ldy;
-  hipLaunchKernelGGL((bn_pair_apply_kernel<T, VEC>), A.grid, A.block, (size_t)3 * A.block.x * VEC * sizeof(float), st, (const T*)xa,
-                     (const T*)xb, (T*)y, sums_a, sums_b, gamma_a, beta_a, gamma_b, beta_b, rm_a, rv_a, rm_b, rv_b, save_a, save_b, g);
+#define PAIR_APPLY(ACT_)                                                                                                               \
+  hipLaunchKernelGGL((bn_pair_apply_kernel<T, VEC, ACT_>), A.grid, A.block, (size_t)3 * A.block.x * VEC * sizeof(float), st, (const T*)xa, \
+                     (const T*)xb, (T*)y, sums_a, sums_b, gamma_a, beta_a, gamma_b, beta_b, rm_a, rv_a, rm_b, rv_b, save_a, save_b, g)
+  if (act == ACT_SILU) PAIR_APPLY(ACT_SILU); else PAIR_APPLY(-1);
+#undef PAIR_APPLY
   DFINE_LAUNCH_CHECK();
   return 0;
 }
@@ -770,13 +819,19 @@ static int pair_bwd_impl(const void* xa, const void* xb, const void* dy, int ld_
   NaGeom g = make_geom(n_pix, C, R.ppt, act, false, false, training, eps, 0.f);
   g.ld_dy = ld_dy, g.ld_dy2 = ld_dy2;
   const size_t lds_r = (size_t)R.block.x * VEC * sizeof(float) * (R.block.y * 3 > 7 ? R.block.y * 3 : 7);
-  hipLaunchKernelGGL((bn_pair_bwd_reduce_kernel<T, VEC>), R.grid, R.block, lds_r, st, (const T*)xa, (const T*)xb, (const T*)dy,
-                     (const T*)dy2, save_a, save_b, gamma_a, beta_a, gamma_b, beta_b, red, g);
+#define PAIR_RED(ACT_)                                                                                                        \
+  hipLaunchKernelGGL((bn_pair_bwd_reduce_kernel<T, VEC, ACT_>), R.grid, R.block, lds_r, st, (const T*)xa, (const T*)xb, (const T*)dy, \
+                     (const T*)dy2, save_a, save_b, gamma_a, beta_a, gamma_b, beta_b, red, g)
+  if (act == ACT_SILU) PAIR_RED(ACT_SILU); else PAIR_RED(-1);
+#undef PAIR_RED
   DFINE_LAUNCH_CHECK();
   g.pix_per_thread = A.ppt;
-  hipLaunchKernelGGL((bn_pair_bwd_dx_kernel<T, VEC>), A.grid, A.block, (size_t)10 * A.block.x * VEC * sizeof(float), st, (const T*)xa,
-                     (const T*)xb, (const T*)dy, (const T*)dy2, save_a, save_b, gamma_a, beta_a, gamma_b, beta_b, red, (T*)dxa, (T*)dxb,
-                     dgamma_a, dbeta_a, dgamma_b, dbeta_b, g);
+#define PAIR_DX(ACT_)                                                                                                                   \
+  hipLaunchKernelGGL((bn_pair_bwd_dx_kernel<T, VEC, ACT_>), A.grid, A.block, (size_t)10 * A.block.x * VEC * sizeof(float), st, (const T*)xa, \
+                     (const T*)xb, (const T*)dy, (const T*)dy2, save_a, save_b, gamma_a, beta_a, gamma_b, beta_b, red, (T*)dxa, (T*)dxb,   \
+                     dgamma_a, dbeta_a, dgamma_b, dbeta_b, g)
+  if (act == ACT_SILU) PAIR_DX(ACT_SILU); else PAIR_DX(-1);
+#undef PAIR_DX
   DFINE_LAUNCH_CHECK();
   return 0;
 }

@@ -152,7 +152,12 @@ class _MSDeformAttnCore(torch.autograd.Function):
 import os as _os
 
 MSDA_VALUE_GRAD = "slab" if _os.environ.get("DFINE_MSDA_VALUE", "") == "slab" else "atomic"
-MSDA_GRAD_BF16 = _os.environ.get("DFINE_MSDA_GRAD", "bf16") != "f32"  # "atomic" mode with bf16 values: packed bf16 atomics
+# "atomic" mode with bf16 values: float atomics into an fp32 map by default -- what the reference's AMP path does (grid_sample
+# is on autocast's fp32 list, so its backward accumulates in fp32). DFINE_MSDA_GRAD=bf16 selects PACKED bf16 atomics into a
+# bf16 map: half the atomic bytes (384 vs 630 us per layer at D-FINE-m batch 32) but the running sum is rounded to 8 bits at
+# every add; where many sampling points pile onto a few memory tokens the sum swamps (tests/test_bf16_wellcond_gpu.py: backbone
+# gradient cosine to the reference -0.5 with it, 0.61 with float atomics, in a fixture whose query boxes all coincide).
+MSDA_GRAD_BF16 = _os.environ.get("DFINE_MSDA_GRAD", "f32") == "bf16"
 
 
 class ValueGradSink:

@@ -10,6 +10,16 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
+# The fp32 parity runs (amp off) go through F.conv2d = MIOpen. MIOpen's gfx950 assembly implicit-GEMM backward-data kernel
+# for NHWC (`igemm_bwd_gtcx35_nhwc_fp32_*`, solver ConvAsmImplicitGemmGTCDynamicBwdXdlopsNHWC) accesses memory past the end
+# of an operand: harmless unless that operand is the last block of a mapped allocator segment, then "Memory access fault by
+# GPU" (first byte of the next, unmapped 2 MiB page) -- which is why the round-2 fault came and went with the allocator
+# state earlier tests left behind. Named by running the suite with serialised launches and AMD_LOG_LEVEL=3
+# (profiles/r03_fault_diag_launch_tail.txt: the last launch before the fault, deterministically, at the stem's 3-channel
+# conv). The solver is switched off for the test processes (children inherit it); MIOpen falls back to its other solvers.
+# The benchmarked bf16 path never calls MIOpen.
+os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -214,7 +214,8 @@ def test_bf16_stage_errors_are_bounded_and_below_stock_autocast(hip_lib, tmp_pat
             assert prod_b[lvl] < 0.6 * stock[0][lvl], ("backbone", lvl, prod_b[lvl], stock[0][lvl])
             assert prod_e[lvl] < stock[1][lvl], ("encoder", lvl, prod_e[lvl], stock[1][lvl])
     if stock is None:
-        pytest.skip("the stock bf16 pipeline (MIOpen) crashed in its child process: only the absolute bounds were checked")
+        pytest.xfail("the stock bf16 pipeline died in its child process (MIOpen igemm_bwd_gtcx35_nhwc_* over-read, see "
+                     "tests/conftest.py): only the absolute bounds were checked")
 
 
 def _step_gradients(amp, stock):
@@ -257,10 +258,11 @@ def test_bf16_train_step_gradients_vs_fp32_and_stock_autocast(hip_lib, tmp_path)
     encoder / decoder. (Measured, whole model: product 0.65, stock autocast 0.59 -- with random weights and BatchNorm over 2
     images NO bf16 pipeline tracks the fp32 gradient closely, see profiles/r02_bf16_error_by_layer.txt; the product must not be
     the worse of the two.)
-    The STOCK pipeline runs in a child process: MIOpen's bf16 BatchNorm / convolution kernels have faulted on this GPU
-    ("Memory access fault", autograd thread inside an ATen node) depending on what the allocator hands them -- on D-FINE-n's
-    21-channel maps always, on this model when the suite's earlier tests leave the heap in a certain state. If the child dies
-    the comparison (b) is skipped and only the absolute bound (a) is enforced."""
+    The STOCK pipeline runs in a child process: MIOpen's assembly implicit-GEMM NHWC backward-data kernel
+    (igemm_bwd_gtcx35_nhwc_*) reads past the end of an operand and faults when that operand ends an allocator segment
+    (cause and evidence: tests/conftest.py, profiles/r03_fault_diag_launch_tail.txt); that solver is now switched off for
+    the test processes, the child process stays as a second line of defence for the yardstick. If the child dies the
+    comparison (b) is reported as xfail and only the absolute bound (a) is enforced."""
     g32, g_prod = _step_gradients(False, False), _step_gradients(True, False)
     g_stock = _in_child(_stock_gradients_worker, str(tmp_path / "stock_grads.pt"))
 
@@ -276,7 +278,8 @@ def test_bf16_train_step_gradients_vs_fp32_and_stock_autocast(hip_lib, tmp_path)
             c_stock = cos(g_stock, g32, prefix)
             assert c_prod >= c_stock - 0.03, (prefix, c_prod, c_stock)
     if g_stock is None:
-        pytest.skip("the stock bf16 pipeline (MIOpen) crashed in its child process: only the fp32 bound was checked")
+        pytest.xfail("the stock bf16 pipeline died in its child process (MIOpen igemm_bwd_gtcx35_nhwc_* over-read, see "
+                     "tests/conftest.py): only the fp32 bound was checked")
 
 
 @pytest.mark.parametrize("fname", ["model_m640", "model_m640_seg"])

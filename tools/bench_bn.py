@@ -70,7 +70,11 @@ def run(label):
         del x, dy, y
 
 
-if "--sweep" in sys.argv:
+if "--tail" in sys.argv:  # where does the backward reduction's time go: full, without its global atomics, without any column reduction
+    for dbg in ("0", "1", "2"):
+        os.environ["DFINE_BN_DEBUG"] = dbg
+        run(f"DFINE_BN_DEBUG={dbg}")
+elif "--sweep" in sys.argv:
     for rb, un in itertools.product((512, 1024, 2048), (2, 4, 8)):
         os.environ["DFINE_BN_REDUCE_BLOCKS"], os.environ["DFINE_BN_BWD_UNROLL"] = str(rb), str(un)
         run(f"reduce blocks {rb}, bwd unroll {un}")
