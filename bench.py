@@ -103,8 +103,11 @@ TIMER_TO_DEVICE_KERNEL = {
     "fdr_head_fwd": "fdr_head_fwd_kernel", "fdr_head_bwd": "fdr_head_bwd_kernel", "stem_pool_fwd": "pool_fwd_kernel",
     "stem_pool_bwd": "pool_bwd_kernel", "add_layernorm_fwd": "add_ln_fwd_kernel", "add_layernorm_bwd": "add_ln_bwd_kernel",
     "mask_loss_stats": "mask_stats_kernel", "mask_loss_grad": "mask_grad_kernel",
-    # one kernel family behind four call sites: dense conv forward / input gradient, Linear forward / input gradient
+    # the implicit GEMM's two bodies: gathers (k x k / strided convs) and unaligned shapes on the register-staged igemm_kernel,
+    # plain rows (1x1 convs, Linears, the mask contraction) on the LDS-DMA ring igemm2_kernel
     "conv_fwd": "igemm_kernel", "conv_dgrad": "igemm_kernel", "gemm_fwd": "igemm_kernel", "gemm_dgrad": "igemm_kernel",
+    "conv_fwd_rows": "igemm2_kernel", "conv_dgrad_rows": "igemm2_kernel", "gemm_fwd_rows": "igemm2_kernel",
+    "gemm_dgrad_rows": "igemm2_kernel", "mask_rows_stats": "igemm2_kernel", "mask_rows_dz": "igemm2_kernel",
     "attention_fwd": "attn_fwd_kernel", "attention_bwd": "attn_bwd_dkv_kernel", "transpose_weights": "transpose_weights_kernel",
     "embedding_wgrad": "embedding_wgrad_kernel", "msda_bwd_points": "msda_bwd_kernel", "msda_bwd_value": "msda_bwd_value_kernel",
 }

@@ -431,6 +431,7 @@ class DFINETransformer(nn.Module):
         res["enc_aux_outputs"] = [{"pred_logits": topk_logits, "pred_boxes": torch.sigmoid(enc_bbox_unact)}]
         res["pre_outputs"] = {"pred_logits": reg_part(pre_logits), "pred_boxes": reg_part(pre_boxes)}
         res["enc_meta"] = {"class_agnostic": False}
+        res["enc_topk_ind"] = topk_ind  # the query selection of this forward (int64 [B, Q]); not a key of the reference's dict
         dn_masks = [dn_part(e) for e in embeds] if do_masks else None
         # detection: every layer's dn head; with masks the reference's zip truncates to L-1 layers and
         # carries the last layer's dn masks separately (:1059-1070)

@@ -69,6 +69,10 @@ def _launch(A, Bw, C, bias, stats, g, name, detail):
     if _os.environ.get("DFINE_IGEMM_DEBUG"):  # diagnostics of the LDS-DMA body: 8 = no MFMA, 16 = no DMA (tools/bench_igemm_cfg.py)
         g.act |= int(_os.environ["DFINE_IGEMM_DEBUG"]) << 8
     _lib.require_gpu(A, Bw, C)
+    # timer names say which kernel body serves the launch (csrc/igemm.hip dispatch): plain rows on the 16-byte path -> the
+    # LDS-DMA ring (igemm2_kernel, "<site>_rows"), everything else -> the register-staged body (igemm_kernel)
+    if not g.gather and g.K % 8 == 0 and g.lda % 8 == 0 and g.ldb % 8 == 0 and A.data_ptr() % 16 == 0 and Bw.data_ptr() % 16 == 0:
+        name += "_rows"
     nbytes = (g.M * (g.CI if g.gather else g.K) + g.M * g.N + g.N * g.K) * 2
     with _lib.timed(name, nbytes, detail, flops=2.0 * g.M * g.N * g.K):
         rc = lib.dfine_igemm_bf16(_lib.ptr(A), _lib.ptr(Bw), _lib.ptr(C), _lib.ptr(bias), _lib.ptr(stats), ctypes.byref(g),

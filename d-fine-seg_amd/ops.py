@@ -1018,7 +1018,7 @@ class _MaskRowsLoss(torch.autograd.Function):
             rows_t = torch.zeros(B, C, Npad, dtype=torch.bfloat16, device=fl.device)
             rows_t[:, :, :N] = r.transpose(1, 2)
             d_feat = torch.empty(B * HW, C, dtype=torch.bfloat16, device=fl.device)
-            with _lib.timed("gemm_dgrad", (dz.numel() + d_feat.numel() + rows_t.numel()) * 2, "mask d_feat", flops=2.0 * B * HW * Npad * C):
+            with _lib.timed("gemm_dgrad_rows", (dz.numel() + d_feat.numel() + rows_t.numel()) * 2, "mask d_feat", flops=2.0 * B * HW * Npad * C):
                 rc = lib.dfine_mask_rows_dfeat(_lib.ptr(dz), Npad, _lib.ptr(rows_t), Npad, _lib.ptr(d_feat), B, HW, Npad, C, _lib.stream_ptr())
             _lib.check(rc, "dfine_mask_rows_dfeat")
             d_feat = d_feat.view(B, H, W, C).permute(0, 3, 1, 2)

@@ -481,6 +481,9 @@ int dfine_gate_mix_bwd(const void* pre, const void* a, const void* b, const void
  *   outputs, spread over 8 replicas -- the layout dfine_bn_act_fwd reads, so a BatchNorm after the conv skips its
  *   statistics pass. Any alignment is accepted (16-byte vector path when CI (gather) / K (plain), lda, ldb are
  *   multiples of 8 and the bases are 16-byte aligned; 8-byte and element-wise paths otherwise).
+ *   Two kernel bodies serve it, bit-identical in their results: plain rows on the 16-byte path run on an LDS-DMA ring
+ *   (csrc/igemm2.hip: `buffer_load ... lds`, counted s_waitcnt, hardware range check instead of zero-fill branches), gathers
+ *   and the narrow paths on the register-staged body (csrc/igemm.hip). DFINE_IGEMM_V=1|2 forces one body (measurements).
  * ------------------------------------------------------------------------------------- */
 #define DFINE_IGEMM_MAX_TAPS 16
 typedef struct dfine_igemm_geom {

@@ -25,8 +25,9 @@ for r in rows:
     n = r["Kernel_Name"]
     if "wgrad_group_kernel" in n: k = "dfine::wgrad_group_kernel (grouped weight gradients)"
     elif "wgrad_kernel" in n: k = "dfine::wgrad_kernel (single-problem weight gradients: stem)"
+    elif "dfine::igemm2_kernel" in n: k = "dfine::igemm2_kernel, plain rows on the LDS-DMA ring (1x1 conv + Linear forward / input gradient)"
     elif "dfine::igemm_kernel" in n and "true>" in n.split("(")[0]: k = "dfine::igemm_kernel, gathered (k x k / strided conv forward + input gradient)"
-    elif "dfine::igemm_kernel" in n: k = "dfine::igemm_kernel, plain rows (1x1 conv + Linear forward / input gradient)"
+    elif "dfine::igemm_kernel" in n: k = "dfine::igemm_kernel, plain rows that are not on the 16-byte path (odd K / pitches)"
     elif "dfine::attn" in n: k = "dfine::attn_* (self-attention forward / backward)"
     elif "igemm_fwd" in n or "conv_fwd" in n: k = "MIOpen conv forward (igemm asm / CK xdl)"
     elif "igemm_bwd" in n or "conv_bwd_data" in n: k = "MIOpen conv input-gradient (igemm asm / CK xdl)"

@@ -23,6 +23,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in rows:
     n = r["Kernel_Name"]
     if "wgrad_group_kernel" in n: k = "wgrad_group_kernel"
+    elif "igemm2_kernel" in n: k = "igemm2_kernel (plain rows, LDS-DMA ring)"
     elif "igemm_kernel" in n and "true>" in n.split("(")[0]: k = "igemm_kernel gathered"
     elif "igemm_kernel" in n: k = "igemm_kernel plain rows"
     else: continue
