@@ -57,9 +57,9 @@ def test_deployed_bf16_eval_against_the_reference_golden(hip_lib):
     """The deployed model (norms folded into convs, RepVgg branches merged) through the bf16 inference path against the
     REFERENCE's eval outputs (tests/golden/model_m640.npz: eval-mode forward, running statistics = well-defined
     normalisation). bf16 runs its own top-k, so queries are matched by box: every golden query must have a predicted query
-    within 2e-2 L1 of its box for >= 90 % of the queries, and on those the class logits agree to 0.25 relative L2 (the
-    name-hashed weights amplify bf16 rounding through ~60 layers, DESIGN.md 4: the encoder maps are tens of percent from
-    fp32 in ANY bf16 pipeline; boxes and logits are much better conditioned than the maps)."""
+    within 2e-2 L1 of its box for >= 97 % of the queries, and on those the class logits agree to 2e-2 relative L2
+    (measured: 99.3 % matched, 2.4e-3 -- eval-mode norms divide by the running statistics, which is well conditioned even
+    with the name-hashed weights; the few unmatched queries are selection swaps at the 300th rank)."""
     from conftest import load_golden
     from dfine_seg_amd.dfine import build_model
 
@@ -81,5 +81,5 @@ def test_deployed_bf16_eval_against_the_reference_golden(hip_lib):
         fracs.append(float(ok.float().mean()))
         rels.append(float((got_l[b][idx[ok]] - ref_l[b][ok]).norm() / ref_l[b][ok].norm()))
     print("\n[deployed bf16 vs golden eval] matched fraction", fracs, "logit rel-L2 on matched", rels)
-    assert min(fracs) >= 0.9, fracs
-    assert max(rels) <= 0.25, rels
+    assert min(fracs) >= 0.97, fracs
+    assert max(rels) <= 2e-2, rels
