@@ -236,10 +236,15 @@ def main():
     timer = _lib.KernelTimer(by_detail=args.shapes)
     graph_was_on, trainer.use_graph = trainer.use_graph, False
     _lib.set_kernel_timer(timer)
+    from dfine_seg_amd import ops as _ops
+
+    _ops.bnred_counts.update(fused=0, discarded=0)
     for _ in range(probe_steps):
         trainer.step(images, targets)
     sync()
     _lib.set_kernel_timer(None)
+    if rank == 0:  # norm backwards whose reduction pass a GEMM epilogue replaced / epilogue sums that went unused, per step
+        print("bn backward reductions per step:", {k: v // probe_steps for k, v in _ops.bnred_counts.items()}, file=sys.stderr)
     trainer.use_graph = graph_was_on
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)

@@ -49,6 +49,7 @@ SIGNATURES = {
     "dfine_grad_sumsq": [_c_void_p, ctypes.c_longlong, _c_void_p, _c_void_p],
     "dfine_adamw_ema_step": [_c_void_p] * 8 + [ctypes.POINTER(ctypes.c_longlong), _c_int, ctypes.c_longlong, _c_void_p],
     "dfine_igemm_bf16": [_c_void_p] * 7,
+    "dfine_igemm_bf16_bnred": [_c_void_p] * 6,
     "dfine_msda_bwd_points": [_c_void_p, _c_int] + [_c_void_p] * 5 + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
     "dfine_msda_bwd_value": [_c_int] + [ctypes.POINTER(_c_void_p)] * 3 + [_c_int, _c_void_p] + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
     "dfine_mask_targets_nearest": [_c_void_p, _c_void_p, ctypes.c_longlong] + [_c_int] * 6 + [_c_void_p],
@@ -73,7 +74,7 @@ SIGNATURES = {
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int, _c_void_p, _c_int, _c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 _lib = None
 
 IGEMM_MAX_TAPS = 16
@@ -86,6 +87,13 @@ class IGemmGeom(ctypes.Structure):
                                       "isy", "isx", "OHf", "OWf", "osy", "osx", "ooy", "oox", "act")] + [
         ("tap_dy", ctypes.c_byte * IGEMM_MAX_TAPS), ("tap_dx", ctypes.c_byte * IGEMM_MAX_TAPS),
         ("tap_w", ctypes.c_byte * IGEMM_MAX_TAPS)]
+
+
+class IGemmBnRed(ctypes.Structure):
+    """dfine_igemm_bnred of include/dfine_hip.h (host struct, passed by pointer)."""
+
+    _fields_ = [(n, _c_void_p) for n in ("x", "dy2", "mean", "rstd", "gamma", "beta", "lab_scale", "red")] + [
+        (n, _c_int) for n in ("ldx", "ld_dy2", "act")]
 
 
 class WgradProblem(ctypes.Structure):

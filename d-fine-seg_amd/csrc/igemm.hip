@@ -32,6 +32,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "igemm_bnred.h"
 
 namespace dfine {
 
@@ -64,11 +65,11 @@ struct IgRow {  // one staged pixel row: decoded once, constant over the K loop
   bool ok;
 };
 
-template <int FM, int FN, int BK, int VEC, int OVEC, bool GATHER>
+template <int FM, int FN, int BK, int VEC, int OVEC, bool GATHER, bool BNRED = false>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bw,
                                                       bf16_t* __restrict__ C, const float* __restrict__ bias,
                                                       double* __restrict__ stats, const IGemmGeom g, int m_tiles,
-                                                      int n_tiles, int m_per_xcd) {
+                                                      int n_tiles, int m_per_xcd, const IgBnRed br) {
   constexpr int BM = 32 * FM, BN = 32 * FN;
   constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
   constexpr int RPP = 256 / CPR;              // rows staged per pass of the 256 threads
@@ -271,6 +272,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const bf16_t* __restrict_
   const int ncol = n0 + o_j * 8;
   const int nvalid = min(max(g.N - ncol, 0), 8);
   const bool accumulate = (g.act & 0x400) != 0;
+  BnRedLane brl;  // igemm_bnred.h: the producing norm's backward sums over this tile (input-gradient launches)
+  if (BNRED) brl.init(br, ncol, nvalid == 8);
 #pragma unroll
   for (int i = 0; i < BM / ORPP; ++i) {
     const int ml = o_r + i * ORPP, m = m0 + ml;
@@ -298,6 +301,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const bf16_t* __restrict_
           r[q] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
         }
         *reinterpret_cast<uint4*>(dst) = make_uint4(r[0], r[1], r[2], r[3]);
+        if (BNRED) brl.row(br, r, orow / g.ldc, ncol);  // the SUM is the finished gradient
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -306,6 +310,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const bf16_t* __restrict_
       }
     } else if (OVEC == 8 && nvalid == 8) {
       *reinterpret_cast<uint4*>(dst) = v;
+      if (BNRED) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        brl.row(br, w, orow / g.ldc, ncol);
+      }
     } else {
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -341,6 +349,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const bf16_t* __restrict_
         atomicAdd(stats + ((size_t)(blockIdx.x & 7) * 2 + q) * g.N + n0 + c, (double)acc);
     }
   }
+  if (BNRED) {
+    float* part = reinterpret_cast<float*>(lds_raw + BM * CPITCH * 2);  // [2][ORPP][BN]
+    bnred_columns<BN, ORPP, 256>(part, brl.a[0], brl.a[1], o_r, o_j, tid, br.red, 0, g.N, n0, (g.act & 0x2000) != 0);
+    if (br.lab_scale != nullptr) bnred_columns<BN, ORPP, 256>(part, brl.a[2], brl.a[3], o_r, o_j, tid, br.red, 2, g.N, n0, (g.act & 0x2000) != 0);
+  }
 }
 
 static inline int ig_tile_n(int N) {
@@ -355,16 +368,16 @@ static inline int ig_tile_n(int N) {
   return best;
 }
 
-template <int FN, int BK, int VEC, int OVEC, bool GATHER>
+template <int FN, int BK, int VEC, int OVEC, bool GATHER, bool BNRED = false>
 static int ig_launch(const void* A, const void* Bw, void* C, const float* bias, double* stats, const IGemmGeom& g,
-                     hipStream_t stream) {
+                     hipStream_t stream, const IgBnRed& br = IgBnRed{}) {
   constexpr int BM = 128, BN = 32 * FN;
   const int m_tiles = (g.M + BM - 1) / BM, n_tiles = (g.N + BN - 1) / BN;
   const int m_per_xcd = (m_tiles + 7) / 8;
   const long long grid = 8LL * m_per_xcd * n_tiles;
   if (grid > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
-  hipLaunchKernelGGL((igemm_kernel<4, FN, BK, VEC, OVEC, GATHER>), dim3((unsigned)grid), dim3(256), 0, stream,
-                     (const bf16_t*)A, (const bf16_t*)Bw, (bf16_t*)C, bias, stats, g, m_tiles, n_tiles, m_per_xcd);
+  hipLaunchKernelGGL((igemm_kernel<4, FN, BK, VEC, OVEC, GATHER, BNRED>), dim3((unsigned)grid), dim3(256), 0, stream,
+                     (const bf16_t*)A, (const bf16_t*)Bw, (bf16_t*)C, bias, stats, g, m_tiles, n_tiles, m_per_xcd, br);
   DFINE_LAUNCH_CHECK();
   return 0;
 }
@@ -408,6 +421,25 @@ static int ig_dispatch_k(const void* A, const void* Bw, void* C, const float* bi
   return ig_dispatch_n<32, VEC, OVEC, GATHER>(A, Bw, C, bias, stats, g, stream);
 }
 
+// the gathered input gradient with the producing norm's reductions in the epilogue: 16-byte paths only
+static int ig_dispatch_bnred(const void* A, const void* Bw, void* C, const IGemmGeom& g, const IgBnRed& br, hipStream_t st) {
+  const long long m_tiles = (g.M + 127) / 128;
+  int bn = ig_tile_n(g.N);
+  while (bn > 32 && m_tiles * ((g.N + bn - 1) / bn) < 200) bn >>= 1;
+  const int pad64 = (g.K + 63) / 64 * 64, pad32 = (g.K + 31) / 32 * 32;
+  const bool use64 = (pad64 == pad32 && g.K > 64) || g.K >= 1024;
+#define IG_BR(FN_, BK_) return ig_launch<FN_, BK_, 8, 8, true, true>(A, Bw, C, nullptr, nullptr, g, st, br)
+  if (use64) {
+    if (bn == 128) IG_BR(4, 64);
+    if (bn == 64) IG_BR(2, 64);
+    IG_BR(1, 64);
+  }
+  if (bn == 128) IG_BR(4, 32);
+  if (bn == 64) IG_BR(2, 32);
+  IG_BR(1, 32);
+#undef IG_BR
+}
+
 template <int VEC, int OVEC>
 static int ig_dispatch_g(const void* A, const void* Bw, void* C, const float* bias, double* stats, const IGemmGeom& g,
                          hipStream_t stream) {
@@ -417,14 +449,14 @@ static int ig_dispatch_g(const void* A, const void* Bw, void* C, const float* bi
 
 // igemm2.hip: the LDS-DMA ring body for operands on the 16-byte path
 int igemm2_run(const void* A, const void* Bw, void* C, const float* bias, double* stats, const IGemmGeom& g,
-               long long a_extent, bool ovec8, hipStream_t st);
+               long long a_extent, bool ovec8, hipStream_t st, const IgBnRed* br);
 
 }  // namespace dfine
 
 using namespace dfine;
 
-extern "C" int dfine_igemm_bf16(const void* A, const void* Bw, void* C, const float* bias, double* stats,
-                                const dfine_igemm_geom* geom, void* stream) {
+static int igemm_entry(const void* A, const void* Bw, void* C, const float* bias, double* stats, const dfine_igemm_geom* geom,
+                       const IgBnRed* br, void* stream) {
   if (!A || !Bw || !C || !geom) return DFINE_E_BADARG;
   const IGemmGeom& g = *geom;
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.lda <= 0 || g.ldb < 0 || g.ldc < g.N) return DFINE_E_BADARG;
@@ -466,11 +498,35 @@ extern "C" int dfine_igemm_bf16(const void* A, const void* Bw, void* C, const fl
   const char* fb = getenv("DFINE_IGEMM_V");  // read per call: tools/bench_igemm_cfg.py switches it at run time
   const int forced_body = fb ? atoi(fb) : 0;
   const bool use_v2 = forced_body == 2 || (forced_body != 1 && !g.gather);
+  if (br != nullptr) {  // input gradient + the producing norm's backward reductions (igemm_bnred.h)
+    if (vec != 8 || !ovec8 || g.N % 8 != 0 || stats || bias) return DFINE_E_UNSUPPORTED;
+    if (!g.gather) return igemm2_run(A, Bw, C, bias, stats, g, a_extent, ovec8, st, br);
+    return ig_dispatch_bnred(A, Bw, C, g, *br, st);
+  }
   if (vec == 8 && use_v2) {
-    const int rc = igemm2_run(A, Bw, C, bias, stats, g, a_extent, ovec8, st);
+    const int rc = igemm2_run(A, Bw, C, bias, stats, g, a_extent, ovec8, st, nullptr);
     if (rc != DFINE_E_UNSUPPORTED) return rc;
   }
   if (vec == 8) return ovec8 ? ig_dispatch_g<8, 8>(A, Bw, C, bias, stats, g, st) : ig_dispatch_g<8, 1>(A, Bw, C, bias, stats, g, st);
   if (vec == 4) return ovec8 ? ig_dispatch_g<4, 8>(A, Bw, C, bias, stats, g, st) : ig_dispatch_g<4, 1>(A, Bw, C, bias, stats, g, st);
   return ovec8 ? ig_dispatch_g<1, 8>(A, Bw, C, bias, stats, g, st) : ig_dispatch_g<1, 1>(A, Bw, C, bias, stats, g, st);
+}
+
+extern "C" int dfine_igemm_bf16(const void* A, const void* Bw, void* C, const float* bias, double* stats,
+                                const dfine_igemm_geom* geom, void* stream) {
+  return igemm_entry(A, Bw, C, bias, stats, geom, nullptr, stream);
+}
+
+extern "C" int dfine_igemm_bf16_bnred(const void* A, const void* Bw, void* C, const dfine_igemm_geom* geom,
+                                      const dfine_igemm_bnred* bnred, void* stream) {
+  if (!bnred || !bnred->x || !bnred->mean || !bnred->rstd || !bnred->gamma || !bnred->beta || !bnred->red) return DFINE_E_BADARG;
+  if (bnred->ldx < geom->N || (bnred->dy2 && bnred->ld_dy2 < geom->N) || bnred->act < 0 || bnred->act > 2) return DFINE_E_BADARG;
+  if (bnred->ldx % 8 != 0 || (bnred->dy2 && bnred->ld_dy2 % 8 != 0) || (uintptr_t)bnred->x % 16 != 0 ||
+      (bnred->dy2 && (uintptr_t)bnred->dy2 % 16 != 0))
+    return DFINE_E_UNSUPPORTED;
+  IgBnRed br;
+  br.x = (const bf16_t*)bnred->x, br.dy2 = (const bf16_t*)bnred->dy2;
+  br.mean = bnred->mean, br.rstd = bnred->rstd, br.gamma = bnred->gamma, br.beta = bnred->beta, br.lab_scale = bnred->lab_scale;
+  br.red = bnred->red, br.ldx = bnred->ldx, br.ld_dy2 = bnred->ld_dy2, br.act = bnred->act;
+  return igemm_entry(A, Bw, C, nullptr, nullptr, geom, &br, stream);
 }

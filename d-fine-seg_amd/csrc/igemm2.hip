@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "igemm_bnred.h"
 #include "maskmath.h"
 
 namespace dfine {
@@ -56,7 +57,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 //                   nothing else is written;
 //   EPI_MASK_DZ     the accumulators are turned into d(loss)/d(logit) in place (given d(loss)/d(stats)) and leave through
 //                   the ordinary store path as a bf16 [B*HW, N] matrix -- the operand of the two backward GEMMs.
-enum { EPI_PLAIN = 0, EPI_MASK_STATS = 1, EPI_MASK_DZ = 2 };
+enum { EPI_PLAIN = 0, EPI_MASK_STATS = 1, EPI_MASK_DZ = 2, EPI_BNRED = 3 };  // EPI_BNRED: igemm_bnred.h
 struct Ig2Mask {
   const float* tgt;     // [B][G][HW] fp32 ground-truth masks at the logit resolution
   const float* alpha;   // [B][G]
@@ -90,10 +91,11 @@ struct Ig2Cfg {
 };
 
 template <int WM, int WN, int FMW, int FNW, int BK, int NS, bool PIPE, bool GATHER, int EPI>
-__global__ __launch_bounds__(WM * WN * 64, (Ig2Cfg<WM, WN, FMW, FNW, BK, NS>::WAVES_PER_SIMD)) void igemm2_kernel(
+__global__ __launch_bounds__(WM * WN * 64, ((EPI == 3 && Ig2Cfg<WM, WN, FMW, FNW, BK, NS>::WAVES_PER_SIMD > 3)
+                                                 ? 3 : Ig2Cfg<WM, WN, FMW, FNW, BK, NS>::WAVES_PER_SIMD)) void igemm2_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ Bw, bf16_t* __restrict__ C, const float* __restrict__ bias,
     double* __restrict__ stats, const IGemmGeom g, int m_tiles, int n_tiles, int m_per_xcd, unsigned a_bytes, unsigned b_bytes,
-    int ovec8, const Ig2Mask mk) {
+    int ovec8, const Ig2Mask mk, const IgBnRed br) {
   typedef Ig2Cfg<WM, WN, FMW, FNW, BK, NS> Cfg;
   constexpr int NT = Cfg::NT, NW = Cfg::NW, BM = Cfg::BM, BN = Cfg::BN;
   constexpr int CPR = BK / 8, RPI = Cfg::RPI;
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(WM * WN * 64, (Ig2Cfg<WM, WN, FMW, FNW, BK, NS>::WA
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (n_steps == 0 never happens: K >= 1)
   __syncthreads();  // every wave is done with the ring: the epilogue reuses it
 
-  if (EPI != EPI_PLAIN) {
+  if (EPI == EPI_MASK_STATS || EPI == EPI_MASK_DZ) {
     // the mask logits of this tile are the accumulators: accumulator quad (i, j) = rows n_base .. n_base+3 of pixel px
     const int px0 = m0 - img * mk.HW + wave_m * RM + f_r;
     float sf[FNW][4], si[FNW][4], sp[FNW][4];
@@ -376,6 +378,8 @@ __global__ __launch_bounds__(WM * WN * 64, (Ig2Cfg<WM, WN, FMW, FNW, BK, NS>::WA
   const int ncol = n0 + o_j * 8;
   const int nvalid = min(max(g.N - ncol, 0), 8);
   const bool accumulate = (g.act & 0x400) != 0;
+  BnRedLane brl;
+  if (EPI == EPI_BNRED) brl.init(br, ncol, nvalid == 8);
 #pragma unroll
   for (int h = 0; h < EH; ++h) {
     if (h > 0) __syncthreads();  // the previous block's tile and partials have been read
@@ -437,6 +441,7 @@ __global__ __launch_bounds__(WM * WN * 64, (Ig2Cfg<WM, WN, FMW, FNW, BK, NS>::WA
             r[q] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
           }
           *reinterpret_cast<uint4*>(dst) = make_uint4(r[0], r[1], r[2], r[3]);
+          if (EPI == EPI_BNRED) brl.row(br, r, orow / g.ldc, ncol);  // the SUM is the finished gradient
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
@@ -445,6 +450,10 @@ __global__ __launch_bounds__(WM * WN * 64, (Ig2Cfg<WM, WN, FMW, FNW, BK, NS>::WA
         }
       } else if (ovec8 && nvalid == 8) {
         *reinterpret_cast<uint4*>(dst) = v;
+        if (EPI == EPI_BNRED) {
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+          brl.row(br, w, orow / g.ldc, ncol);
+        }
       } else {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -478,12 +487,20 @@ __global__ __launch_bounds__(WM * WN * 64, (Ig2Cfg<WM, WN, FMW, FNW, BK, NS>::WA
           atomicAdd(stats + ((size_t)(blockIdx.x & 7) * 2 + q) * g.N + n0 + c, (double)a);
       }
     }
+    if (EPI == EPI_BNRED) {
+      float* part = reinterpret_cast<float*>(lds_raw + BMH * CPITCH * 2);  // [2][ORPP][BN]
+      bnred_columns<BN, ORPP, NT>(part, brl.a[0], brl.a[1], o_r, o_j, tid, br.red, 0, g.N, n0, (g.act & 0x2000) != 0);
+      if (br.lab_scale != nullptr) bnred_columns<BN, ORPP, NT>(part, brl.a[2], brl.a[3], o_r, o_j, tid, br.red, 2, g.N, n0, (g.act & 0x2000) != 0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) brl.a[0][e] = brl.a[1][e] = brl.a[2][e] = brl.a[3][e] = 0.f;
+    }
   }
 }
 
 template <int WM, int WN, int FMW, int FNW, int BK, int NS, bool PIPE, bool GATHER, int EPI = EPI_PLAIN>
 static int ig2_launch(const void* A, const void* Bw, void* C, const float* bias, double* stats, const IGemmGeom& g,
-                      unsigned a_bytes, unsigned b_bytes, bool ovec8, hipStream_t stream, const Ig2Mask mk = Ig2Mask{}) {
+                      unsigned a_bytes, unsigned b_bytes, bool ovec8, hipStream_t stream, const Ig2Mask mk = Ig2Mask{},
+                      const IgBnRed br = IgBnRed{}) {
   typedef Ig2Cfg<WM, WN, FMW, FNW, BK, NS> Cfg;
   const int m_tiles = (g.M + Cfg::BM - 1) / Cfg::BM, n_tiles = (g.N + Cfg::BN - 1) / Cfg::BN;
   const int m_per_xcd = (m_tiles + 7) / 8;
@@ -491,7 +508,7 @@ static int ig2_launch(const void* A, const void* Bw, void* C, const float* bias,
   if (grid > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
   hipLaunchKernelGGL((igemm2_kernel<WM, WN, FMW, FNW, BK, NS, PIPE, GATHER, EPI>), dim3((unsigned)grid), dim3(Cfg::NT), 0, stream,
                      (const bf16_t*)A, (const bf16_t*)Bw, (bf16_t*)C, bias, stats, g, m_tiles, n_tiles, m_per_xcd, a_bytes, b_bytes,
-                     (int)ovec8, mk);
+                     (int)ovec8, mk, br);
   DFINE_LAUNCH_CHECK();
   return 0;
 }
@@ -503,7 +520,7 @@ static int env_int(const char* name, int dflt) {
 
 template <bool GATHER>
 static int ig2_dispatch(const void* A, const void* Bw, void* C, const float* bias, double* stats, const IGemmGeom& g,
-                        unsigned a_bytes, unsigned b_bytes, bool ovec8, hipStream_t st) {
+                        unsigned a_bytes, unsigned b_bytes, bool ovec8, hipStream_t st, const IgBnRed* br) {
   // DFINE_IGEMM2_CFG=<wm><wn><fmw><fnw><bk/32><ns><pipe> (e.g. 2244130) forces one configuration for A/B measurements
   const int forced = env_int("DFINE_IGEMM2_CFG", 0);  // read per call: tools/bench_igemm_cfg.py switches it at run time
   // default: 128-row tiles; N tile as in igemm.hip (padded columns vs A re-reads), halved while the grid cannot fill the chip
@@ -520,6 +537,14 @@ static int ig2_dispatch(const void* A, const void* Bw, void* C, const float* bia
   while (bn > 32 && m_tiles * ((g.N + bn - 1) / bn) < 200) bn >>= 1;
   int cfg = 2240130 + (bn / 32) * 1000;  // 128 x bn, 4 waves, K step 32, 3 stages
   if (forced) cfg = forced;
+  if (br != nullptr) {  // the producing norm's backward reductions in the epilogue (igemm_bnred.h): default tiles only
+    if (GATHER || !ovec8 || g.N % 8 != 0 || stats != nullptr) return DFINE_E_UNSUPPORTED;
+    switch (bn) {
+      case 128: return ig2_launch<2, 2, 4, 4, 32, 3, false, false, EPI_BNRED>(A, Bw, C, bias, stats, g, a_bytes, b_bytes, ovec8, st, Ig2Mask{}, *br);
+      case 64: return ig2_launch<2, 2, 4, 2, 32, 3, false, false, EPI_BNRED>(A, Bw, C, bias, stats, g, a_bytes, b_bytes, ovec8, st, Ig2Mask{}, *br);
+      default: return ig2_launch<2, 2, 4, 1, 32, 3, false, false, EPI_BNRED>(A, Bw, C, bias, stats, g, a_bytes, b_bytes, ovec8, st, Ig2Mask{}, *br);
+    }
+  }
 #define IG2_CASE(WM_, WN_, FMW_, FNW_, BK_, NS_, P_)                                                               \
   if (cfg == WM_ * 1000000 + WN_ * 100000 + FMW_ * 10000 + FNW_ * 1000 + (BK_ / 32) * 100 + NS_ * 10 + P_) \
     return ig2_launch<WM_, WN_, FMW_, FNW_, BK_, NS_, P_ != 0, GATHER>(A, Bw, C, bias, stats, g, a_bytes, b_bytes, ovec8, st);
@@ -543,11 +568,11 @@ static int ig2_dispatch(const void* A, const void* Bw, void* C, const float* bia
 
 // called by dfine_igemm_bf16 (igemm.hip) after its argument checks, for operands on the 16-byte path
 int igemm2_run(const void* A, const void* Bw, void* C, const float* bias, double* stats, const IGemmGeom& g,
-               long long a_extent, bool ovec8, hipStream_t st) {
+               long long a_extent, bool ovec8, hipStream_t st, const IgBnRed* br) {
   const long long a_bytes = a_extent * 2, b_bytes = (long long)g.N * g.ldb * 2;
   if (a_bytes > 0xFFFFFF00LL || b_bytes > 0xFFFFFF00LL) return DFINE_E_UNSUPPORTED;  // 32-bit buffer offsets
-  return g.gather ? ig2_dispatch<true>(A, Bw, C, bias, stats, g, (unsigned)a_bytes, (unsigned)b_bytes, ovec8, st)
-                  : ig2_dispatch<false>(A, Bw, C, bias, stats, g, (unsigned)a_bytes, (unsigned)b_bytes, ovec8, st);
+  return g.gather ? ig2_dispatch<true>(A, Bw, C, bias, stats, g, (unsigned)a_bytes, (unsigned)b_bytes, ovec8, st, br)
+                  : ig2_dispatch<false>(A, Bw, C, bias, stats, g, (unsigned)a_bytes, (unsigned)b_bytes, ovec8, st, br);
 }
 
 

@@ -62,11 +62,26 @@ import os as _os
 _NO_PUBLISH = bool(_os.environ.get("DFINE_IGEMM_STATS_NOPUBLISH"))  # diagnostic (tools/bench_igemm_cold.py)
 
 
-def _launch(A, Bw, C, bias, stats, g, name, detail):
+class BnRed:
+    """What an input-gradient launch needs to take the PRODUCING norm's backward sums in its epilogue (include/dfine_hip.h:
+    dfine_igemm_bf16_bnred): the norm's input x [n_pix, C] bf16 pixel rows, the optional second gradient part (a channel
+    slice of a concat buffer's gradient), saved mean / rstd, gamma / beta, LAB scale, activation code and the zeroed fp64
+    reduction workspace (as its fp32 view)."""
+
+    __slots__ = ("x", "dy2", "mean", "rstd", "gamma", "beta", "lab_scale", "red", "act")
+
+    def __init__(self, x, dy2, mean, rstd, gamma, beta, lab_scale, red, act):
+        self.x, self.dy2, self.mean, self.rstd, self.gamma, self.beta = x, dy2, mean, rstd, gamma, beta
+        self.lab_scale, self.red, self.act = lab_scale, red, act
+
+
+def _launch(A, Bw, C, bias, stats, g, name, detail, bnred=None):
+    """``bnred`` (a BnRed): try the launch with the norm reductions in its epilogue; returns True when that form ran, False
+    when the plain launch ran (shapes off the 16-byte paths)."""
     lib = _lib.load()
     if _NO_PUBLISH:
         g.act |= int(_os.environ["DFINE_IGEMM_STATS_NOPUBLISH"]) << 8
-    if _os.environ.get("DFINE_IGEMM_DEBUG"):  # diagnostics of the LDS-DMA body: 8 = no MFMA, 16 = no DMA (tools/bench_igemm_cfg.py)
+    if _os.environ.get("DFINE_IGEMM_DEBUG"):  # diagnostics: 8 = no MFMA, 16 = no DMA (LDS-DMA body, tools/bench_igemm_cfg.py), 32 = bnred epilogue without its atomics
         g.act |= int(_os.environ["DFINE_IGEMM_DEBUG"]) << 8
     _lib.require_gpu(A, Bw, C)
     # timer names say which kernel body serves the launch (csrc/igemm.hip dispatch): plain rows on the 16-byte path -> the
@@ -74,10 +89,26 @@ def _launch(A, Bw, C, bias, stats, g, name, detail):
     if not g.gather and g.K % 8 == 0 and g.lda % 8 == 0 and g.ldb % 8 == 0 and A.data_ptr() % 16 == 0 and Bw.data_ptr() % 16 == 0:
         name += "_rows"
     nbytes = (g.M * (g.CI if g.gather else g.K) + g.M * g.N + g.N * g.K) * 2
+    if bnred is not None and bias is None and stats is None:
+        ldx = pixel_pitch(bnred.x)
+        ld2 = pixel_pitch(bnred.dy2) if bnred.dy2 is not None else 0
+        if ldx is not None and ld2 is not None:
+            br = _lib.IGemmBnRed(x=bnred.x.data_ptr(), dy2=bnred.dy2.data_ptr() if bnred.dy2 is not None else None,
+                                 mean=bnred.mean.data_ptr(), rstd=bnred.rstd.data_ptr(), gamma=bnred.gamma.data_ptr(),
+                                 beta=bnred.beta.data_ptr(), lab_scale=bnred.lab_scale.data_ptr() if bnred.lab_scale is not None else None,
+                                 red=bnred.red.data_ptr(), ldx=ldx, ld_dy2=ld2, act=bnred.act)
+            extra = (g.M * g.N * (2 if bnred.dy2 is not None else 1)) * 2
+            with _lib.timed(name, nbytes + extra, detail + " +bnred", flops=2.0 * g.M * g.N * g.K):
+                rc = lib.dfine_igemm_bf16_bnred(_lib.ptr(A), _lib.ptr(Bw), _lib.ptr(C), ctypes.byref(g), ctypes.byref(br), _lib.stream_ptr())
+            if rc == 0:
+                return True
+            if rc != -2:
+                _lib.check(rc, "dfine_igemm_bf16_bnred")
     with _lib.timed(name, nbytes, detail, flops=2.0 * g.M * g.N * g.K):
         rc = lib.dfine_igemm_bf16(_lib.ptr(A), _lib.ptr(Bw), _lib.ptr(C), _lib.ptr(bias), _lib.ptr(stats), ctypes.byref(g),
                                   _lib.stream_ptr())
     _lib.check(rc, "dfine_igemm_bf16")
+    return False
 
 
 def _check_bf16(*ts):
@@ -136,9 +167,10 @@ def conv_forward(x, w_khwc, stride=1, pad=0, pad_br=None, out=None, stats=None, 
     return out
 
 
-def conv_input_grad(gy, wt_ckhwk, in_hw, stride=1, pad=0, out=None, accumulate=False):
+def conv_input_grad(gy, wt_ckhwk, in_hw, stride=1, pad=0, out=None, accumulate=False, bnred=None):
     """gy [B, OH, OW, CO] pixel rows, wt [CI, KH, KW, CO] dense bf16 (the transposed weight) -> dx [B, H, W, CI].
-    ``accumulate`` (stride 1, with ``out``): out += dx in the GEMM's epilogue."""
+    ``accumulate`` (stride 1, with ``out``): out += dx in the GEMM's epilogue. ``bnred`` (a BnRed, stride 1 only): the norm
+    that produced this conv's input gets its backward sums from the launch's epilogue; ``out._bnred_done`` says whether it did."""
     _check_bf16(gy, wt_ckhwk)
     gy, lda = as_pixel_rows(gy)
     B, OH, OW, CO = gy.shape
@@ -153,9 +185,11 @@ def conv_input_grad(gy, wt_ckhwk, in_hw, stride=1, pad=0, out=None, accumulate=F
     acc = 0x400 if accumulate else 0
     if accumulate and stride != 1:
         raise _lib.DfineHipError("conv_input_grad: accumulate is for stride-1 convolutions")
+    if bnred is not None and stride != 1:
+        bnred = None
     if KH == 1 and KW == 1 and stride == 1 and pad == 0:
         g = _geom(M=B * H * W, N=CI, K=CO, lda=lda, ldb=CO, ldc=ldc, gather=0, act=acc)
-        _launch(gy, wt_ckhwk, out, None, None, g, "conv_dgrad", detail)
+        out._bnred_done = _launch(gy, wt_ckhwk, out, None, None, g, "conv_dgrad", detail, bnred)
         return out
     classes = []
     for ey in range(stride):
@@ -172,7 +206,7 @@ def conv_input_grad(gy, wt_ckhwk, in_hw, stride=1, pad=0, out=None, accumulate=F
             continue
         g = _geom(M=B * ph * pw, N=CI, K=len(taps) * CO, lda=lda, ldb=KH * KW * CO, ldc=ldc, gather=1, PH=ph, PW=pw, IH=OH, IW=OW,
                   CI=CO, isy=1, isx=1, OHf=H, OWf=W, osy=stride, osx=stride, ooy=ey, oox=ex, taps=taps, act=acc)
-        _launch(gy, wt_ckhwk, out, None, None, g, "conv_dgrad", detail)
+        out._bnred_done = _launch(gy, wt_ckhwk, out, None, None, g, "conv_dgrad", detail, bnred)
     return out
 
 

@@ -549,6 +549,59 @@ def concat_buffer_supported(x, channel_counts):
             and all(c % 8 == 0 for c in channel_counts))
 
 
+# off by default: measured on D-FINE-m 640 b32 the 50 served norms save 1.1 ms of reduction launches but their GEMMs' epilogues
+# (x tile read + activation derivative per element, exposed after the K loop) cost 2.1 ms -- DESIGN.md section 3, "not kept"
+BNRED_FUSION = os.environ.get("DFINE_BNRED", "0") == "1"
+bnred_counts = {"fused": 0, "discarded": 0}  # norm backwards served by a GEMM epilogue / epilogue sums that went unused
+_last_bn_handle = None
+
+
+class BnBackwardHandle:
+    """Lets the ONE stride-1 dense conv that consumes a fused norm's output take that norm's backward reductions in its
+    input-gradient GEMM's epilogue (dfine_igemm_bf16_bnred) -- the norm's backward then runs its dx pass only. Made by
+    _BatchNormAct.forward, hung on the output tensor by ``batch_norm_act`` and picked up by ``dense_conv``.
+
+    The sums are only valid when the gradient the norm's backward receives IS the tensor that launch wrote (autograd summed
+    nothing onto it) and the concat-slice part (dy2) is the one the launch read: ``token`` records both, the norm's backward
+    compares and otherwise zeroes the workspace and reduces by itself."""
+
+    __slots__ = ("xl", "mean", "rstd", "g32", "b32", "ls32", "act", "slot", "consumers", "ws", "token")
+
+    def __init__(self, xl, mean, rstd, g32, b32, ls32, act, slot):
+        self.xl, self.mean, self.rstd, self.g32, self.b32, self.ls32, self.act, self.slot = xl, mean, rstd, g32, b32, ls32, act, slot
+        self.consumers, self.ws, self.token = 0, None, None
+
+    def slot_grad(self):
+        C = self.xl.shape[-1]
+        if self.slot is None or self.slot[0].grad is None:
+            return None, 0
+        return _grad_rows(self.slot[0].grad[..., self.slot[1] : self.slot[1] + C].to(self.xl.dtype), C)
+
+    def begin(self, in_hw):
+        """The BnRed for the consumer's input-gradient launch, or None when this norm cannot be served."""
+        from . import gemm
+
+        B, H, W, C = self.xl.shape
+        if not BNRED_FUSION or self.consumers != 1 or self.token is not None or tuple(in_hw) != (H, W):
+            return None
+        gy2, _ = self.slot_grad()
+        self.ws = zeros_f32(66 * C + 2, self.xl.device)
+        self.token = ("open", (gy2.data_ptr(), gy2._version) if gy2 is not None else None)
+        return gemm.BnRed(self.xl, gy2, self.mean, self.rstd, self.g32, self.b32, self.ls32, self.ws[: 64 * C], _ACT_CODES[self.act])
+
+    def finish(self, dx_rows, done):
+        if not done:  # shapes off the 16-byte paths: the plain launch ran and the workspace is untouched
+            self.ws, self.token = None, ("plain",)
+            return
+        self.token = ("done", self.token[1], dx_rows.data_ptr(), dx_rows._version)
+
+    def matches(self, gy, gy2):
+        """True when ``gy`` / ``gy2`` (what the norm's backward is about to read) are what the fused launch summed over."""
+        t = self.token
+        return (t is not None and t[0] == "done" and t[1] == ((gy2.data_ptr(), gy2._version) if gy2 is not None else None)
+                and t[2] == gy.data_ptr() and t[3] == gy._version)
+
+
 class _BatchNormAct(torch.autograd.Function):
     """BN (batch statistics, or frozen/running statistics) + addend + activation + LAB; see
     include/dfine_hip.h (dfine_bn_act_*)."""
@@ -600,6 +653,11 @@ class _BatchNormAct(torch.autograd.Function):
         ctx.save_for_backward(xl, al, g32, b32, save_mean, save_rstd, ls32)
         ctx.cfg = (act, eps, int(training), gamma.dtype, lab_scale.dtype if lab_scale is not None else None)
         ctx.params = (gamma, beta, lab_scale, lab_bias)
+        global _last_bn_handle
+        ctx.handle = None
+        if (al is None and xl.dtype == torch.bfloat16 and C % 8 == 0 and BNRED_FUSION
+                and (training or gamma.requires_grad or beta.requires_grad)):
+            ctx.handle = _last_bn_handle = BnBackwardHandle(xl, save_mean, save_rstd, g32, b32, ls32, act, slot)
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -626,7 +684,13 @@ class _BatchNormAct(torch.autograd.Function):
         dx = torch.empty_like(xl)
         dadd = torch.empty_like(xl) if al is not None else None
         # one zeroed workspace: fp64 reductions [8 replicas][4C] (as 64C floats) | dgamma [C] | dbeta [C] | dlab [2]
-        ws = zeros_f32(66 * C + 2, xl.device)
+        h, reduced = ctx.handle, False
+        if h is not None and h.ws is not None and h.matches(gy, gy2):  # the consumer's input-gradient GEMM left the reductions
+            ws, reduced = h.ws, True
+            bnred_counts["fused"] += 1
+        else:  # (sums of a gradient autograd has since added to are dropped with their workspace)
+            ws = zeros_f32(66 * C + 2, xl.device)
+            bnred_counts["discarded"] += int(h is not None and h.ws is not None)
         red, dgamma, dbeta, dlab = ws[: 64 * C], ws[64 * C : 65 * C], ws[65 * C : 66 * C], ws[66 * C :]
         gamma_p, beta_p, ls_p, lb_p = ctx.params
         plist = [gamma_p, beta_p] + ([ls_p, lb_p] if ls32 is not None else [])
@@ -646,7 +710,7 @@ class _BatchNormAct(torch.autograd.Function):
                 _lib.ptr(dbeta), _lib.ptr(dls) if ls32 is not None else None, _lib.ptr(dlb) if ls32 is not None else None,
                 n_pix, C, _ACT_CODES[act], training, eps)
         rc = 0
-        if training or wants_param_grads:  # the reductions feed the batch-statistics terms and the parameter gradients
+        if (training or wants_param_grads) and not reduced:  # the reductions feed the batch-statistics terms and the parameter gradients
             with _lib.timed("bn_bwd_reduce", ((2 + n_dy) * xl.numel() - xl.numel() + n_add) * es, f"{n_pix}x{C}"):
                 rc = lib.dfine_bn_act_bwd(*args, 1, _lib.stream_ptr())
         with _lib.timed("bn_bwd_dx", ((2 + n_dy) * xl.numel() + 2 * n_add) * es, f"{n_pix}x{C}"):
@@ -767,8 +831,14 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, lab_scal
     nn.BatchNorm2d (momentum, unbiased variance)."""
     if x.dtype not in (torch.float32, torch.bfloat16):
         x = x.float()
-    return _BatchNormAct.apply(x, addend, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, float(eps),
-                               float(momentum), bool(training), ws, bool(have_stats), slot, post)
+    global _last_bn_handle
+    _last_bn_handle = None
+    y = _BatchNormAct.apply(x, addend, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, float(eps),
+                            float(momentum), bool(training), ws, bool(have_stats), slot, post)
+    if _last_bn_handle is not None and y.requires_grad:
+        y._bn_handle = _last_bn_handle  # see BnBackwardHandle
+    _last_bn_handle = None
+    return y
 
 
 def batch_norm_act_supported(x, channels):
@@ -1677,9 +1747,12 @@ class _DenseConv(torch.autograd.Function):
     split-M kernel with gathered rows, accumulated straight into the fp32 .grad."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding, pad_br, stats, out):
+    def forward(ctx, x, weight, stride, padding, pad_br, stats, out, bn_handle=None):
         from . import gemm
 
+        ctx.bn_handle = bn_handle if stride == 1 else None
+        if bn_handle is not None:
+            bn_handle.consumers += 1
         x16 = x.to(torch.bfloat16)
         xl = gemm.nhwc(x16)
         if gemm.pixel_pitch(xl) is None:
@@ -1710,9 +1783,14 @@ class _DenseConv(torch.autograd.Function):
         OH, OW = gyl.shape[1], gyl.shape[2]
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = gemm.conv_input_grad(gyl, bf16_t_of(weight), (H, W), stride, padding).permute(0, 3, 1, 2)
+            h = ctx.bn_handle
+            br = h.begin((H, W)) if h is not None else None
+            dxl = gemm.conv_input_grad(gyl, bf16_t_of(weight), (H, W), stride, padding, bnred=br)
+            if br is not None:
+                h.finish(dxl, dxl._bnred_done)
+            dx = dxl.permute(0, 3, 1, 2)
         dw = _conv_weight_grad(weight, gyl, xl, stride, padding)
-        return dx, dw, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None
 
 
 def _conv_weight_grad(weight, gyc, xc, stride, padding):
@@ -1758,9 +1836,12 @@ class _DenseConvPair(torch.autograd.Function):
     instead of autograd summing two maps with an extra kernel -- and two (queued) weight gradients."""
 
     @staticmethod
-    def forward(ctx, x, wa, wb, pad_a, pad_b, stats_a, stats_b):
+    def forward(ctx, x, wa, wb, pad_a, pad_b, stats_a, stats_b, bn_handle=None):
         from . import gemm
 
+        ctx.bn_handle = bn_handle
+        if bn_handle is not None:
+            bn_handle.consumers += 1
         xl = gemm.nhwc(x.to(torch.bfloat16))
         if gemm.pixel_pitch(xl) is None:
             xl = xl.contiguous()
@@ -1784,27 +1865,31 @@ class _DenseConvPair(torch.autograd.Function):
             return gl if gemm.pixel_pitch(gl) is not None else gl.contiguous()
 
         dx, dwa, dwb = None, None, None
-        for g, w, pad in ((ga, wa, pad_a), (gb, wb, pad_b)):
-            if g is None:
-                continue
+        live = [(g, w, pad) for g, w, pad in ((ga, wa, pad_a), (gb, wb, pad_b)) if g is not None]
+        for i, (g, w, pad) in enumerate(live):
             gl = rows(g)
             if ctx.needs_input_grad[0]:
+                # the launch that FINISHES the input gradient takes the producing norm's backward sums (BnBackwardHandle)
+                h = ctx.bn_handle if i == len(live) - 1 else None
+                br = h.begin((H, W)) if h is not None else None
                 if dx is None:
-                    dx = gemm.conv_input_grad(gl, bf16_t_of(w), (H, W), 1, pad)
+                    dx = gemm.conv_input_grad(gl, bf16_t_of(w), (H, W), 1, pad, bnred=br)
                 else:
-                    gemm.conv_input_grad(gl, bf16_t_of(w), (H, W), 1, pad, out=dx, accumulate=True)
+                    gemm.conv_input_grad(gl, bf16_t_of(w), (H, W), 1, pad, out=dx, accumulate=True, bnred=br)
+                if br is not None:
+                    h.finish(dx, dx._bnred_done)
             dw = _conv_weight_grad(w, gl, xl, 1, pad)
             if w is wa:
                 dwa = dw
             else:
                 dwb = dw
-        return (dx.permute(0, 3, 1, 2) if dx is not None else None), dwa, dwb, None, None, None, None
+        return (dx.permute(0, 3, 1, 2) if dx is not None else None), dwa, dwb, None, None, None, None, None
 
 
 def dense_conv_pair(x, weight_a, weight_b, pad_a, pad_b, stats_a=None, stats_b=None):
     """(F.conv2d(x, weight_a, padding=pad_a), F.conv2d(x, weight_b, padding=pad_b)) for two stride-1 dense convs of one input,
     bf16 GPU path (see _DenseConvPair). ``stats_*``: as in ``dense_conv``."""
-    return _DenseConvPair.apply(x, weight_a, weight_b, int(pad_a), int(pad_b), stats_a, stats_b)
+    return _DenseConvPair.apply(x, weight_a, weight_b, int(pad_a), int(pad_b), stats_a, stats_b, getattr(x, "_bn_handle", None))
 
 
 def _is_khwc(t):
@@ -1835,7 +1920,7 @@ def dense_conv(x, weight, stride=1, padding=0, pad_br=None, stats=None, out=None
         yl = gemm.conv_forward(xl, _khwc(bf16_of(weight)), stride, padding, pad_br, out=gemm.nhwc(out) if out is not None else None,
                                stats=stats)
         return out if out is not None else yl.permute(0, 3, 1, 2)
-    return _DenseConv.apply(x, weight, int(stride), int(padding), pad_br, stats, out)
+    return _DenseConv.apply(x, weight, int(stride), int(padding), pad_br, stats, out, getattr(x, "_bn_handle", None))
 
 
 def conv_bias_act(x, conv, act=None, addend=None):

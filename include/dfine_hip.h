@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 18
+#define DFINE_ABI_VERSION 19
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -497,6 +497,25 @@ typedef struct dfine_igemm_geom {
 } dfine_igemm_geom;
 int dfine_igemm_bf16(const void* A, const void* Bw, void* C, const float* bias, double* stats,
                      const dfine_igemm_geom* geom /* host */, void* stream);
+
+/* The same GEMM as an INPUT-GRADIENT launch whose output is d(loss)/d(y) for y = lab(act(bn(x))), the previous layer's fused
+ * norm (reference hgnetv2.py:35-80, hybrid_encoder.py:21-45): the epilogue also reads the norm's input x (and the optional
+ * second gradient part dy2 of a y that was written into a concat slice) and adds that norm's backward sums
+ *     red[replica][0..3][n] += ( sum dz, sum dz*xhat, sum dy*act(z), sum dy ),   dz = (dy + dy2) * lab_scale * act'(z)
+ * (the pass dfine_bn_act_bwd phase 1 makes) -- dfine_bn_act_bwd then runs with phase = 2 only. With geom->act & 0x400
+ * (C += result) the sums are taken over the finished sum. x bf16 [rows of the output map, ldx], dy2 bf16 [.., ld_dy2] or NULL,
+ * mean / rstd / gamma / beta f32 [N], lab_scale f32 [1] or NULL (then entries 2, 3 are untouched), red = zeroed fp64 [8][4][N].
+ * Needs the 16-byte paths (as dfine_igemm_bf16) and N, ldx, ld_dy2 multiples of 8; DFINE_E_UNSUPPORTED otherwise (the
+ * caller then makes the plain launch + the reduction pass). */
+typedef struct dfine_igemm_bnred {
+  const void* x;
+  const void* dy2;
+  const float *mean, *rstd, *gamma, *beta, *lab_scale;
+  double* red;
+  int ldx, ld_dy2, act;
+} dfine_igemm_bnred;
+int dfine_igemm_bf16_bnred(const void* A, const void* Bw, void* C, const dfine_igemm_geom* geom /* host */,
+                           const dfine_igemm_bnred* bnred /* host */, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Transposed bf16 copies of weights for the input-gradient GEMMs: for each of n weights

@@ -178,3 +178,87 @@ def test_bn_pair_act_matches_torch_fp32(hip_lib, B, C, H, W, dtype):
         torch.testing.assert_close(n.bias.grad.cpu(), nr.bias.grad, **ptol)
         torch.testing.assert_close(n.running_mean.cpu(), nr.running_mean, rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(n.running_var.cpu(), nr.running_var, rtol=1e-3, atol=1e-5)
+
+
+def _bn_conv_chain(fused, B, C, H, W, K, ksize, act, with_lab, with_slot, branch):
+    """x -> fused norm (+act, +LAB, optionally into a concat slice that a second reader also takes) -> stride-1 dense conv;
+    returns (dx, dgamma, dbeta, dlab_scale, dlab_bias, dw, handle token)."""
+    from dfine_seg_amd import ops
+
+    torch.manual_seed(11)
+    dev = "cuda"
+    x = (torch.randn(B, C, H, W, device=dev) * 1.5 + 0.3).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+    gamma = (torch.rand(C, device=dev) + 0.5).requires_grad_()
+    beta = (torch.randn(C, device=dev) * 0.2).requires_grad_()
+    ls = torch.tensor([1.3], device=dev, requires_grad=True) if with_lab else None
+    lb = torch.tensor([-0.1], device=dev, requires_grad=True) if with_lab else None
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    w = (torch.randn(K, C, ksize, ksize, device=dev) / (C * ksize * ksize) ** 0.5).contiguous(memory_format=torch.channels_last).requires_grad_()
+    w1 = (torch.randn(K, C, 1, 1, device=dev) / C ** 0.5).contiguous(memory_format=torch.channels_last).requires_grad_()
+    r = torch.randn(B, K, H, W, device=dev)
+    old = ops.BNRED_FUSION
+    ops.BNRED_FUSION = fused
+    try:
+        slot, buf = None, None
+        if with_slot:
+            buf = ops.ConcatBuffer(B, H, W, C + 16, torch.bfloat16, dev)
+            slot = (buf, 8)
+        y = ops.batch_norm_act(x, gamma, beta, rm, rv, act=act, lab_scale=ls, lab_bias=lb, training=True, slot=slot)
+        handle = getattr(y, "_bn_handle", None)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if branch == "pair":  # RepVgg's 3x3 + 1x1 of one input: the SECOND (accumulating) launch carries the sums
+                za, zb = ops.dense_conv_pair(y, w, w1, ksize // 2, 0)
+                z = za + 0.5 * zb
+            else:
+                z = ops.dense_conv(y, w, 1, ksize // 2)
+        loss = (z.float() * r).sum()
+        if branch == "second_reader":  # autograd sums two gradients: the fused sums must be discarded
+            loss = loss + (y.float() * 0.25).sum()
+        if with_slot:  # the concat's reader leaves the slice's gradient in the buffer
+            buf.grad = torch.randn(B, H, W, C + 16, device=dev).to(torch.bfloat16)
+        loss.backward()
+    finally:
+        ops.BNRED_FUSION = old
+    return (x.grad.float(), gamma.grad, beta.grad, ls.grad if with_lab else None, lb.grad if with_lab else None, w.grad.float(),
+            handle.token if handle is not None else None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,H,W,K,ksize", [(2, 64, 40, 40, 96, 3), (3, 128, 20, 20, 128, 1), (2, 32, 37, 29, 48, 3), (1, 256, 10, 10, 64, 1),
+                                             (4, 96, 80, 80, 96, 3)])
+@pytest.mark.parametrize("act,with_lab,with_slot", [("relu", True, False), ("silu", False, False), (None, False, True), ("relu", True, True)])
+def test_bn_backward_sums_from_the_consumer_conv_epilogue(hip_lib, B, C, H, W, K, ksize, act, with_lab, with_slot):
+    """dfine_igemm_bf16_bnred: the norm's backward sums taken in the consumer conv's input-gradient epilogue give the same
+    gradients as the norm's own reduction pass (same bf16 inputs, other summation order: 2e-3 relative L2 on dx, 1e-3 on the
+    parameter gradients)."""
+    got = _bn_conv_chain(True, B, C, H, W, K, ksize, act, with_lab, with_slot, None)
+    ref = _bn_conv_chain(False, B, C, H, W, K, ksize, act, with_lab, with_slot, None)
+    assert got[6] is not None and got[6][0] == "done", got[6]
+    assert ref[6] is None
+    for name, a, b, tol in zip(("dx", "dgamma", "dbeta", "dlab_scale", "dlab_bias", "dw"), got[:6], ref[:6], (2e-3, 1e-3, 1e-3, 1e-3, 1e-3, 1e-4)):
+        if a is None:
+            assert b is None
+            continue
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-12))
+        assert rel <= tol, (name, rel)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_slot", [False, True])
+def test_bn_backward_sums_from_a_conv_pair_epilogue(hip_lib, with_slot):
+    got = _bn_conv_chain(True, 2, 128, 20, 20, 128, 3, "silu", False, with_slot, "pair")
+    ref = _bn_conv_chain(False, 2, 128, 20, 20, 128, 3, "silu", False, with_slot, "pair")
+    assert got[6] is not None and got[6][0] == "done", got[6]
+    for name, a, b, tol in zip(("dx", "dgamma", "dbeta"), got[:3], ref[:3], (2e-3, 1e-3, 1e-3)):
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-12))
+        assert rel <= tol, (name, rel)
+
+
+@pytest.mark.gpu
+def test_bn_backward_discards_epilogue_sums_when_autograd_added_a_second_gradient(hip_lib):
+    got = _bn_conv_chain(True, 2, 64, 24, 24, 64, 3, "relu", True, False, "second_reader")
+    ref = _bn_conv_chain(False, 2, 64, 24, 24, 64, 3, "relu", True, False, "second_reader")
+    assert got[6][0] == "done"  # the launch summed, the norm's backward saw another tensor and reduced by itself
+    for name, a, b in zip(("dx", "dgamma", "dbeta", "dlab_scale", "dlab_bias"), got[:5], ref[:5]):
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-12))
+        assert rel <= 1e-5, (name, rel)

@@ -187,3 +187,49 @@ def test_two_convs_of_one_input_form_one_input_gradient(hip_lib, monkeypatch):
         assert torch.equal(y0, y1) and torch.equal(g0, g1)
         for n in p0:  # weight gradients are sums of float atomics (order varies run to run), the rest are plain reductions
             torch.testing.assert_close(p0[n], p1[n], rtol=1e-4, atol=1e-4 * float(p0[n].abs().max()), msg=lambda m: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("B,H,W,CI,CO,k", [(3, 20, 20, 128, 128, 1), (2, 40, 40, 256, 64, 1), (4, 80, 80, 64, 128, 1), (2, 40, 40, 64, 96, 3),
+                                           (2, 20, 20, 384, 128, 3), (1, 7, 9, 32, 48, 1), (8, 80, 80, 128, 128, 1)])
+@pytest.mark.parametrize("act,lab,second", [(1, True, False), (2, False, True), (0, False, False)])
+def test_input_grad_with_norm_backward_sums_in_the_epilogue(hip_lib, igemm_body, B, H, W, CI, CO, k, act, lab, second):
+    """dfine_igemm_bf16_bnred: the input gradient is the plain launch's, and the four per-channel sums (over the 8 fp64
+    replicas) are those of normact.hip's reduction pass computed here in fp64 torch from the same bf16 tensors:
+    sum(dz), sum(dz * xhat), sum(d * act(z)), sum(d); dz = d * lab_scale * act'(z), d = dx + dy2 (1e-4 relative)."""
+    from dfine_seg_amd import gemm
+
+    if igemm_body != "auto":
+        pytest.skip("the bnred launch picks its body by the operand layout alone")
+    torch.manual_seed(5)
+    dev = "cuda"
+    gy = _bf(torch.randn(B, H, W, CO, device=dev))
+    wt = _bf(torch.randn(CI, k, k, CO, device=dev) / (CO * k * k) ** 0.5)
+    x = _bf(torch.randn(B, H, W, CI, device=dev) * 1.3 + 0.2)
+    wide = _bf(torch.randn(B, H, W, CI + 24, device=dev))
+    dy2 = wide[..., 8 : 8 + CI] if second else None
+    mean, rstd = torch.randn(CI, device=dev) * 0.1 + 0.2, torch.rand(CI, device=dev) + 0.5
+    gamma, beta = torch.rand(CI, device=dev) + 0.5, torch.randn(CI, device=dev) * 0.3
+    ls = torch.tensor([1.7], device=dev) if lab else None
+    red = torch.zeros(64 * CI, device=dev)
+    plain = gemm.conv_input_grad(gy, wt, (H, W), 1, k // 2)
+    dx = gemm.conv_input_grad(gy, wt, (H, W), 1, k // 2, bnred=gemm.BnRed(x, dy2, mean, rstd, gamma, beta, ls, red, act))
+    assert dx._bnred_done
+    assert torch.equal(dx, plain)
+    d = dx.double() + (dy2.double() if second else 0)
+    xh = (x.double() - mean.double()) * rstd.double()
+    z = xh * gamma.double() + beta.double()
+    if act == 1:
+        g, f = (z > 0).double(), z.clamp_min(0)
+    elif act == 2:
+        s = torch.sigmoid(z)
+        g, f = s * (1 + z * (1 - s)), z * s
+    else:
+        g, f = torch.ones_like(z), z
+    dz = d * (1.7 if lab else 1.0) * g
+    want = [dz.sum((0, 1, 2)), (dz * xh).sum((0, 1, 2))] + ([(d * f).sum((0, 1, 2)), d.sum((0, 1, 2))] if lab else [])
+    got = red.view(torch.float64).view(8, 4, CI).sum(0)
+    for q, w in enumerate(want):
+        rel = float((got[q] - w).norm() / w.norm())
+        assert rel < 1e-4, (q, rel)
+    if not lab:
+        assert float(got[2:].abs().max()) == 0.0
