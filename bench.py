@@ -210,7 +210,8 @@ def main():
                    ddp.FlatGradAllReduce if args.flat_reducer else ddp.StagedGradAllReduce)
     torch.manual_seed(42 + rank)  # per-rank seed like train.py:131
     trainer = TrainStep(args.model, 80, seg, (args.img, args.img), device, total_steps=max(1000, args.steps + args.warmup + 1),
-                        grad_reducer=reducer, use_graph=not args.no_graph, graph_masks=not args.no_graph_masks)
+                        grad_reducer=reducer, use_graph=not args.no_graph, graph_masks=not args.no_graph_masks,
+                        sync_bn=reducer is not None and args.batch < 4)  # reference train.py:159-160
     images, targets = synthetic_batch(args.batch, args.img, args.img, 80, args.gts, with_masks=seg, seed=42 + rank, device=device)
     images = images.contiguous(memory_format=torch.channels_last)
 

@@ -29,6 +29,7 @@ struct NaGeom {
   int n_pix, C;
   int pix_per_thread;
   int act, has_add, has_lab, training;
+  int ranks;          // SyncBatchNorm: ranks whose AVERAGED sums the workspace holds (1 = this rank's own sums)
   float eps, momentum;
   int ldy;            // forward: pixel pitch of the OUTPUT (>= C: a channel slice of a concat buffer)
   int ld_post;        // forward: pixel pitch of the optional residual added AFTER activation and LAB
@@ -163,7 +164,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
       if (blockIdx.x == 0) {
         save_mean[c] = mean;
         save_rstd[c] = rstd;
-        const float unbiased = g.n_pix > 1 ? var * ((float)g.n_pix / (float)(g.n_pix - 1)) : var;
+        const float count = (float)g.n_pix * (float)g.ranks;  // pixels behind the statistics, over all ranks
+        const float unbiased = count > 1.f ? var * (count / (count - 1.f)) : var;
         running_mean[c] = (1.f - g.momentum) * running_mean[c] + g.momentum * mean;
         running_var[c] = (1.f - g.momentum) * running_var[c] + g.momentum * unbiased;
       }
@@ -451,7 +453,8 @@ __global__ __launch_bounds__(256) void bn_pair_apply_kernel(
         if (blockIdx.x == 0) {
           save[c] = mean;
           save[g.C + c] = rstd;
-          const float unbiased = g.n_pix > 1 ? var * ((float)g.n_pix / (float)(g.n_pix - 1)) : var;
+          const float count = (float)g.n_pix * (float)g.ranks;
+          const float unbiased = count > 1.f ? var * (count / (count - 1.f)) : var;
           rm[c] = (1.f - g.momentum) * rm[c] + g.momentum * mean;
           rv[c] = (1.f - g.momentum) * rv[c] + g.momentum * unbiased;
         }
@@ -722,7 +725,7 @@ static int plan(NaLaunch* L, int n_pix, int C, int target_blocks) {
 static NaGeom make_geom(int n_pix, int C, int ppt, int act, bool has_add, bool has_lab, int training, float eps, float momentum) {
   NaGeom g;
   g.n_pix = n_pix; g.C = C; g.pix_per_thread = ppt; g.act = act; g.has_add = has_add; g.has_lab = has_lab;
-  g.training = training; g.eps = eps; g.momentum = momentum;
+  g.training = training & 0xff; g.ranks = (training >> 8) > 1 ? (training >> 8) : 1; g.eps = eps; g.momentum = momentum;
   g.ldy = g.ld_dy = g.ld_dy2 = g.ld_post = C;
   const char* e = getenv("DFINE_BN_DEBUG");
   g.dbg = e ? atoi(e) : 0;
@@ -862,6 +865,7 @@ extern "C" int dfine_bn_act_fwd(const void* x, const void* addend, void* y, int 
                                 float* running_var, float* save_mean, float* save_rstd,
                                 const float* lab_scale, const float* lab_bias, int n_pix, int C, int act, int training, float eps,
                                 float momentum, int phase, int ldy, const void* post, int ld_post, void* stream) {
+  if ((training & 0xff) == 0) training = 0;  // bits 8..: SyncBatchNorm rank count, meaningful with batch statistics only
   if (!x || !y || !gamma || !beta || !running_mean || !running_var) return DFINE_E_BADARG;
   if (training && (!sums || !save_mean || !save_rstd)) return DFINE_E_BADARG;
   if (n_pix <= 0 || C <= 0 || act < 0 || act > 2 || phase < 0 || phase > 2) return DFINE_E_BADARG;
@@ -887,6 +891,7 @@ extern "C" int dfine_bn_act_bwd(const void* x, const void* addend, const void* d
                                 const float* beta, const float* lab_scale, double* red, void* dx, void* dadd,
                                 float* dgamma, float* dbeta, float* dlab_scale, float* dlab_bias, int n_pix,
                                 int C, int act, int training, float eps, int phase, void* stream) {
+  if ((training & 0xff) == 0) training = 0;  // bits 8..: SyncBatchNorm rank count, meaningful with batch statistics only
   if (!x || !dy || !save_mean || !save_rstd || !gamma || !beta || !red || !dx || !dgamma || !dbeta) return DFINE_E_BADARG;
   if ((addend != nullptr) != (dadd != nullptr)) return DFINE_E_BADARG;
   if (lab_scale && (!dlab_scale || !dlab_bias)) return DFINE_E_BADARG;
@@ -910,6 +915,7 @@ extern "C" int dfine_bn_pair_act_fwd(const void* xa, const void* xb, void* y, in
                                      float* running_mean_a, float* running_var_a, float* running_mean_b, float* running_var_b,
                                      float* save_a, float* save_b, int n_pix, int C, int act, int training, float eps, float momentum,
                                      int ldy, void* stream) {
+  if ((training & 0xff) == 0) training = 0;  // bits 8..: SyncBatchNorm rank count, meaningful with batch statistics only
   if (!xa || !xb || !y || !gamma_a || !beta_a || !gamma_b || !beta_b || !running_mean_a || !running_var_a || !running_mean_b ||
       !running_var_b)
     return DFINE_E_BADARG;
@@ -933,6 +939,7 @@ extern "C" int dfine_bn_pair_act_bwd(const void* xa, const void* xb, const void*
                                      const float* gamma_b, const float* beta_b, double* red, void* dxa, void* dxb, float* dgamma_a,
                                      float* dbeta_a, float* dgamma_b, float* dbeta_b, int n_pix, int C, int act, int training,
                                      float eps, void* stream) {
+  if ((training & 0xff) == 0) training = 0;  // bits 8..: SyncBatchNorm rank count, meaningful with batch statistics only
   if (!xa || !xb || !dy || !save_a || !save_b || !gamma_a || !beta_a || !gamma_b || !beta_b || !red || !dxa || !dxb || !dgamma_a ||
       !dbeta_a || !dgamma_b || !dbeta_b)
     return DFINE_E_BADARG;

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .configs import ModelSpec
-from .layers import MLP, ConvNorm, LayerNorm, Linear, PackedSelfAttention, bias_for_prior
+from .layers import MLP, ConvNorm, LayerNorm, Linear, PackedSelfAttention, bias_for_prior, sync_group_of
 from .targets import TargetBatch
 
 
@@ -189,8 +189,10 @@ class MaskPixelDecoder(nn.Module):
         y = ops.conv_transpose2x2(x, conv.weight, stats) if transposed else ops.dense_conv(x, conv.weight, 1, 0, stats=stats)
         if batch_stats:
             bn.num_batches_tracked.add_(1)
+        sync = sync_group_of(bn) if (batch_stats and isinstance(bn, nn.SyncBatchNorm)) else None
         return ops.batch_norm_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, act, addend=addend,
-                                  training=batch_stats, momentum=bn.momentum or 0.1, eps=bn.eps, ws=ws, have_stats=ws is not None)
+                                  training=batch_stats, momentum=bn.momentum or 0.1, eps=bn.eps, ws=ws, have_stats=ws is not None,
+                                  sync=sync)
 
     def forward(self, feats, enc_s8):
         x = self._conv_bn(self.lateral[0], self.bn[0], feats[0])

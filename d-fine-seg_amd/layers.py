@@ -92,7 +92,7 @@ class ConvNorm(nn.Module):
         (same shape as the output) is added last, after activation and LAB (the HG block's residual), by the same kernel."""
         if into is not None:
             norm = getattr(self, self.norm_name, None)
-            if (x.is_cuda and isinstance(norm, (nn.BatchNorm2d, FrozenBatchNorm2d))
+            if (x.is_cuda and isinstance(norm, (nn.BatchNorm2d, nn.SyncBatchNorm, FrozenBatchNorm2d))
                     and ops.batch_norm_act_supported(x.to(torch.bfloat16) if torch.is_autocast_enabled() else x, self.out_channels)):
                 # the fused norm kernel writes the slice
                 return self._forward(x, addend, act, (into, into.take(self.out_channels)), post)
@@ -125,7 +125,7 @@ class ConvNorm(nn.Module):
         """(ws, have_stats): the norm's workspace when the conv's epilogue is to leave the batch statistics in it."""
         norm = getattr(self, self.norm_name)
         bf16_mode = x.is_cuda and (torch.is_autocast_enabled() or x.dtype == torch.bfloat16)
-        if bf16_mode and self.training and isinstance(norm, nn.BatchNorm2d) and norm.training:
+        if bf16_mode and self.training and isinstance(norm, (nn.BatchNorm2d, nn.SyncBatchNorm)) and norm.training:
             return ops.bn_workspace(self.conv.out_channels, x.device), True
         return None, False
 
@@ -162,15 +162,18 @@ class ConvNorm(nn.Module):
         batch_stats = self.training and not frozen and norm.training
         act_name = act if act is not None else self.act_name
         lab = getattr(self, "lab", None)
-        fused = (isinstance(norm, nn.BatchNorm2d) or frozen) and ops.batch_norm_act_supported(x, conv.out_channels)
+        fused = (isinstance(norm, (nn.BatchNorm2d, nn.SyncBatchNorm)) or frozen) and ops.batch_norm_act_supported(x, conv.out_channels)
         if fused:  # HIP: norm + addend + activation + LAB in 1-2 kernels (2 more in backward); frozen/eval: 1 + 1
             if batch_stats:
                 self._pending_batches += 1
+            sync = None
+            if batch_stats and isinstance(norm, nn.SyncBatchNorm):  # reference train.py:159-160: per-GPU batch < 4 under DDP
+                sync = sync_group_of(norm)
             return ops.batch_norm_act(
                 x, norm.weight, norm.bias, norm.running_mean, norm.running_var, act_name,
                 lab.scale if lab is not None else None, lab.bias if lab is not None else None, addend,
                 training=batch_stats, momentum=getattr(norm, "momentum", 0.1) or 0.1, eps=norm.eps, ws=ws, have_stats=have_stats,
-                slot=slot, post=post)
+                slot=slot, post=post, sync=sync)
         if slot is not None:
             raise ops._lib.DfineHipError("ConvNorm: a concat slot needs the fused norm kernel")
         x = norm(x)
@@ -189,6 +192,18 @@ class ConvNorm(nn.Module):
         if self._pending_batches and getattr(norm, "num_batches_tracked", None) is not None:
             norm.num_batches_tracked += self._pending_batches
         self._pending_batches = 0
+
+
+def sync_group_of(norm):
+    """(process group, ranks) over which an nn.SyncBatchNorm shares its batch statistics, or None when there is nothing to
+    share (no process group initialised, or a single rank) -- nn.SyncBatchNorm.forward then is plain batch norm too."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = norm.process_group  # None = the default group
+    ranks = dist.get_world_size(group)
+    return (group, ranks) if ranks > 1 else None
 
 
 def conv_pair(a, b, x):

@@ -552,6 +552,16 @@ def concat_buffer_supported(x, channel_counts):
 # off by default: measured on D-FINE-m 640 b32 the 50 served norms save 1.1 ms of reduction launches but their GEMMs' epilogues
 # (x tile read + activation derivative per element, exposed after the K loop) cost 2.1 ms -- DESIGN.md section 3, "not kept"
 BNRED_FUSION = os.environ.get("DFINE_BNRED", "0") == "1"
+
+
+def _average_over_ranks(ws32, sync):
+    """The fp64 sums of a norm workspace (handed around as their fp32 view) -> their average over the ranks of ``sync`` =
+    (group, ranks). SUM + scale rather than AVG: gloo (the CPU-side rehearsal backend) has no AVG."""
+    import torch.distributed as dist
+
+    v = ws32.data.view(torch.float64)  # .data: the workspaces are views of one arena whose version counter saved tensors share
+    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=sync[0])
+    v.mul_(1.0 / sync[1])
 bnred_counts = {"fused": 0, "discarded": 0}  # norm backwards served by a GEMM epilogue / epilogue sums that went unused
 _last_bn_handle = None
 
@@ -608,7 +618,7 @@ class _BatchNormAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, addend, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, eps, momentum, training,
-                ws=None, have_stats=False, slot=None, post=None):
+                ws=None, have_stats=False, slot=None, post=None, sync=None):
         _lib.require_gpu(x, gamma, beta)
         lib = _lib.load()
         B, C, H, W = x.shape
@@ -636,13 +646,17 @@ class _BatchNormAct(torch.autograd.Function):
         ls32 = lab_scale.detach().float() if lab_scale is not None else None
         lb32 = lab_bias.detach().float() if lab_bias is not None else None
         es = xl.element_size()
+        # SyncBatchNorm (``sync`` = (process group, ranks)): the sums are averaged over the ranks between the two phases
+        train_code = int(training) | ((sync[1] << 8) if (training and sync is not None) else 0)
         args = (_lib.ptr(xl), _lib.ptr(al), _lib.ptr(y), _lib.dtype_code(xl), _lib.ptr(sums), _lib.ptr(g32), _lib.ptr(b32),
                 _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(save_mean), _lib.ptr(save_rstd), _lib.ptr(ls32),
-                _lib.ptr(lb32), n_pix, C, _ACT_CODES[act], int(training), eps, momentum)
+                _lib.ptr(lb32), n_pix, C, _ACT_CODES[act], train_code, eps, momentum)
         rc = 0
         if training and not have_stats:
             with _lib.timed("bn_stats", xl.numel() * es, f"{n_pix}x{C}"):
                 rc = lib.dfine_bn_act_fwd(*args, 1, ldy, None, 0, _lib.stream_ptr())
+        if training and sync is not None:
+            _average_over_ranks(sums, sync)
         with _lib.timed("bn_apply", (xl.numel() + y.numel() + (al.numel() if al is not None else 0) + (xl.numel() if pl is not None else 0)) * es,
                         f"{n_pix}x{C}"):
             rc = rc or lib.dfine_bn_act_fwd(*args, 2, ldy, _lib.ptr(pl), ld_post, _lib.stream_ptr())
@@ -651,11 +665,12 @@ class _BatchNormAct(torch.autograd.Function):
             save_mean = running_mean.detach().float()
             save_rstd = torch.rsqrt(running_var.detach().float() + eps)
         ctx.save_for_backward(xl, al, g32, b32, save_mean, save_rstd, ls32)
-        ctx.cfg = (act, eps, int(training), gamma.dtype, lab_scale.dtype if lab_scale is not None else None)
+        ctx.cfg = (act, eps, train_code, gamma.dtype, lab_scale.dtype if lab_scale is not None else None)
         ctx.params = (gamma, beta, lab_scale, lab_bias)
+        ctx.sync = sync if training else None
         global _last_bn_handle
         ctx.handle = None
-        if (al is None and xl.dtype == torch.bfloat16 and C % 8 == 0 and BNRED_FUSION
+        if (al is None and xl.dtype == torch.bfloat16 and C % 8 == 0 and BNRED_FUSION and ctx.sync is None
                 and (training or gamma.requires_grad or beta.requires_grad)):
             ctx.handle = _last_bn_handle = BnBackwardHandle(xl, save_mean, save_rstd, g32, b32, ls32, act, slot)
         return y.permute(0, 3, 1, 2)
@@ -673,7 +688,7 @@ class _BatchNormAct(torch.autograd.Function):
             gy2, ld2 = _grad_rows(ctx.slot[0].grad[..., ctx.slot[1] : ctx.slot[1] + C].to(xl.dtype), C)
         if grad_y is None:
             if gy2 is None:
-                return (None,) * 16
+                return (None,) * 17
             gy, ld1, gy2, ld2 = gy2, ld2, None, 0
         else:
             gy, ld1 = _grad_rows(grad_y.to(xl.dtype).permute(0, 2, 3, 1), C)
@@ -713,15 +728,17 @@ class _BatchNormAct(torch.autograd.Function):
         if (training or wants_param_grads) and not reduced:  # the reductions feed the batch-statistics terms and the parameter gradients
             with _lib.timed("bn_bwd_reduce", ((2 + n_dy) * xl.numel() - xl.numel() + n_add) * es, f"{n_pix}x{C}"):
                 rc = lib.dfine_bn_act_bwd(*args, 1, _lib.stream_ptr())
+        if ctx.sync is not None:
+            _average_over_ranks(red, ctx.sync)
         with _lib.timed("bn_bwd_dx", ((2 + n_dy) * xl.numel() + 2 * n_add) * es, f"{n_pix}x{C}"):
             rc = rc or lib.dfine_bn_act_bwd(*args, 2, _lib.stream_ptr())
         _lib.check(rc, "dfine_bn_act_bwd")
         if direct or not wants_param_grads:
-            return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None) + (None,) * 13 + (dpost,)
+            return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None) + (None,) * 13 + (dpost, None)
         return (dx.permute(0, 3, 1, 2), dadd.permute(0, 3, 1, 2) if dadd is not None else None,
                 dgamma.to(g_dtype), dbeta.to(g_dtype), None, None,
                 dlab[0:1].to(lab_dtype) if ls32 is not None else None,
-                dlab[1:2].to(lab_dtype) if ls32 is not None else None, None, None, None, None, None, None, None, dpost)
+                dlab[1:2].to(lab_dtype) if ls32 is not None else None, None, None, None, None, None, None, None, dpost, None)
 
 
 class _BatchNormPairAct(torch.autograd.Function):
@@ -824,17 +841,19 @@ def bn_workspace(channels, device):
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, act=None, lab_scale=None, lab_bias=None,
-                   addend=None, training=True, momentum=0.1, eps=1e-5, ws=None, have_stats=False, slot=None, post=None):
+                   addend=None, training=True, momentum=0.1, eps=1e-5, ws=None, have_stats=False, slot=None, post=None, sync=None):
     """Fused ``lab_scale * act(batch_norm(x) + addend) + lab_bias (+ post)`` on a channels_last map
     (float32 or bfloat16). ``lab_scale`` / ``lab_bias`` are float tensors [1] (both or neither);
     ``act`` is None, "relu" or "silu". In training mode the running statistics are updated in place exactly like
-    nn.BatchNorm2d (momentum, unbiased variance)."""
+    nn.BatchNorm2d (momentum, unbiased variance). ``sync`` = (process group or None for the default one, ranks): the batch
+    statistics are those of all ranks' batches (nn.SyncBatchNorm; every rank must hold the same number of pixels): one small
+    all-reduce of the fp64 sums per direction, see include/dfine_hip.h (dfine_bn_act_fwd, training | R << 8)."""
     if x.dtype not in (torch.float32, torch.bfloat16):
         x = x.float()
     global _last_bn_handle
     _last_bn_handle = None
     y = _BatchNormAct.apply(x, addend, gamma, beta, running_mean, running_var, lab_scale, lab_bias, act, float(eps),
-                            float(momentum), bool(training), ws, bool(have_stats), slot, post)
+                            float(momentum), bool(training), ws, bool(have_stats), slot, post, sync)
     if _last_bn_handle is not None and y.requires_grad:
         y._bn_handle = _last_bn_handle  # see BnBackwardHandle
     _last_bn_handle = None

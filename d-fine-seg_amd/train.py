@@ -104,10 +104,16 @@ class TrainStep:
     def __init__(self, model_name="m", num_classes=80, enable_mask_head=False, img_size=(640, 640),
                  device="cuda", base_lr=1.5e-4, backbone_lr=2e-5, betas=(0.9, 0.999), weight_decay=1.25e-4,
                  clip_max_norm=0.1, use_ema=True, ema_momentum=0.9998, amp=True, total_steps=10000,
-                 pct_start=0.1, grad_reducer=None, use_graph=True, graph_warmup=3, graph_masks=True, overlap_wgrad=False, defer_wgrad=True):
+                 pct_start=0.1, grad_reducer=None, use_graph=True, graph_warmup=3, graph_masks=True, overlap_wgrad=False, defer_wgrad=True,
+                 sync_bn=False):
         self.device = torch.device(device)
         self.num_classes = num_classes
         self.model = build_model(model_name, num_classes, enable_mask_head, self.device, img_size=list(img_size))
+        # reference train.py:159-160: under DDP with a per-GPU batch below 4 every BatchNorm2d becomes a SyncBatchNorm. The
+        # fused norm kernels serve it (ops.batch_norm_act(sync=...): one all-reduce of the fp64 sums per norm and direction)
+        self.sync_bn = bool(sync_bn)
+        if self.sync_bn:
+            self.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.model)
         self.criterion = build_loss(model_name, num_classes, 0.0, enable_mask_head)
         self.ema = ModelEMA(self.model, ema_momentum) if use_ema else None
         self.flat = FlatState(self.model)
@@ -131,7 +137,8 @@ class TrainStep:
             # the EMA copy was taken from this rank's own initial weights BEFORE the reducer broadcast rank 0's: re-seed it
             # from the (now common) live weights and buffers so the averaged model is identical on every rank
             self.sync_ema_to_model()
-        self.use_graph = (use_graph and self.device.type == "cuda"
+        # (SyncBatchNorm issues its per-norm collectives from the host between kernels: such a step is not captured)
+        self.use_graph = (use_graph and self.device.type == "cuda" and not self.sync_bn
                           and (self.grad_reducer is None or getattr(self.grad_reducer, "graph_safe", False)))
         self.graph_warmup = graph_warmup
         self.graph_masks = graph_masks

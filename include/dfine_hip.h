@@ -169,6 +169,11 @@ int dfine_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* wor
  *       the caller before the call
  *   act: 0 identity, 1 ReLU, 2 SiLU.  training=1: batch statistics, running stats updated
  *   (momentum, unbiased variance); training=0 (forward only): running statistics.
+ *   training = 1 | (R << 8), R > 1: SyncBatchNorm over R ranks (reference src/dl/train.py:159-160). The caller has replaced
+ *       `sums` (forward, between phase 1 and phase 2) / `red` (backward, likewise) by their AVERAGE over the ranks, every rank
+ *       holding n_pix pixels: mean, variance and the dx terms then come out as the global ones with no other change, the
+ *       parameter gradients as the mean of the ranks' local ones (what DDP's averaging makes of torch's local sums), and the
+ *       running variance is unbiased with the global count R * n_pix.
  *   training=0 in the backward: dx = gamma * rstd * dz with save_mean / save_rstd = the running statistics
  *       (FrozenBatchNorm2d, src/d_fine/arch/common.py:29-67, and eval-mode BN); phase 1 is then only needed for
  *       dgamma / dbeta / d lab.
