@@ -52,6 +52,9 @@ SIGNATURES = {
     "dfine_igemm_bf16_bnred": [_c_void_p] * 6,
     "dfine_msda_bwd_points": [_c_void_p, _c_int] + [_c_void_p] * 5 + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
     "dfine_msda_bwd_value": [_c_int] + [ctypes.POINTER(_c_void_p)] * 3 + [_c_int, _c_void_p] + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
+    "dfine_msda_bwd_value_sorted": [_c_int] + [ctypes.POINTER(_c_void_p)] * 3 + [_c_int, _c_void_p, _c_void_p, ctypes.c_longlong]
+                                   + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
+    "dfine_msda_sorted_records": [_c_int] * 6,
     "dfine_mask_targets_nearest": [_c_void_p, _c_void_p, ctypes.c_longlong] + [_c_int] * 6 + [_c_void_p],
     "dfine_gate_mix_fwd": [_c_void_p] * 3 + [_c_int, _c_void_p, ctypes.c_longlong, _c_int, _c_void_p],
     "dfine_gate_mix_bwd": [_c_void_p] * 4 + [_c_int] + [_c_void_p] * 3 + [ctypes.c_longlong, _c_int, _c_void_p],
@@ -74,7 +77,7 @@ SIGNATURES = {
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int, _c_void_p, _c_int, _c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 _lib = None
 
 IGEMM_MAX_TAPS = 16
@@ -122,7 +125,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_longlong if name.endswith(("_workspace", "_plan")) else _c_int
+        fn.restype = ctypes.c_longlong if name.endswith(("_workspace", "_plan", "_records")) else _c_int
     got = lib.dfine_abi_version()
     if got != ABI_VERSION:
         raise DfineHipError(f"libdfine_hip.so ABI {got} != expected {ABI_VERSION}: rebuild it")

@@ -124,4 +124,15 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// Workgroups are handed to the 8 XCDs round-robin in launch order, and each XCD has its own L2: when blocks i and i+1 read
+// neighbouring rows of a map (pooling / depthwise / resampling halos), every shared row is fetched from HBM once per XCD
+// (profiles/r03_pmc_traffic.json: stem pool backward 2.6x its algorithmic bytes). Such kernels take their block index from
+// xcd_block_id(): XCD k walks the k-th contiguous eighth of the block range, so neighbours share an L2. The grid must be
+// xcd_grid(n) (a multiple of 8); ids past the real block count fall out at the kernels' own bounds checks.
+__device__ __forceinline__ unsigned xcd_block_id() {
+  const unsigned per = gridDim.x >> 3;
+  return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+}
+static inline unsigned xcd_grid(unsigned n_blocks) { return 8u * ((n_blocks + 7u) / 8u); }
+
 }  // namespace dfine

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
   const int c_base = blockIdx.y * c_slice;
   stage_weights<K>(w_s, w, c_base, c_slice, threadIdx.y * blockDim.x + threadIdx.x, blockDim.x * blockDim.y);
   __syncthreads();
-  const int pix = blockIdx.x * blockDim.y + threadIdx.y;
+  const int pix = xcd_block_id() * blockDim.y + threadIdx.y;
   if (pix >= n_pix) return;
   const int ox = pix % g.OW, oy = (pix / g.OW) % g.OH, b = pix / (g.OW * g.OH);
   const int c_loc = threadIdx.x * VEC;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const T* __restric
   const int c_base = blockIdx.y * c_slice;
   stage_weights<K>(w_s, w, c_base, c_slice, threadIdx.y * blockDim.x + threadIdx.x, blockDim.x * blockDim.y);
   __syncthreads();
-  const int pix = blockIdx.x * blockDim.y + threadIdx.y;  // input pixel
+  const int pix = xcd_block_id() * blockDim.y + threadIdx.y;  // input pixel
   if (pix >= n_pix) return;
   const int ix = pix % g.W, iy = (pix / g.W) % g.H, b = pix / (g.W * g.H);
   const int c_loc = threadIdx.x * VEC;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
   const int c_base = blockIdx.y * c_slice;
   stage_weights<K>(w_s, w, c_base, c_slice, threadIdx.y * blockDim.x + threadIdx.x, blockDim.x * blockDim.y);
   __syncthreads();
-  const int strip = blockIdx.x * blockDim.y + threadIdx.y;
+  const int strip = xcd_block_id() * blockDim.y + threadIdx.y;  // neighbouring strips share an L2 (common.h)
   const bool live = strip < n_strips;
   const int c_loc = threadIdx.x * VEC;
   if (!live && stats == nullptr) return;
@@ -242,7 +242,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
   for (int t = 0; t < K; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[t][i] = 0.f;
-  const int first = blockIdx.x * blockDim.z * rows_per_thread + threadIdx.z;
+  const unsigned bx = xcd_block_id();  // adjacent row ranges (they share K - 1 rows of x) on one XCD's L2 (common.h)
+  if ((long long)bx * blockDim.z * rows_per_thread >= n_rows) return;  // padding blocks of xcd_grid()
+  const int first = bx * blockDim.z * rows_per_thread + threadIdx.z;
   for (int n = 0; n < rows_per_thread; ++n) {
     const int row = first + n * blockDim.z;  // (b, oy)
     if (row >= n_rows) break;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
     }
   }
   // partial sums of this thread's rows: ws[part][c][ky][kx], part = one (block, row-lane) pair
-  float* out = ws + ((size_t)(blockIdx.x * blockDim.z + threadIdx.z) * g.C + c0) * (K * K) + ky * K;
+  float* out = ws + ((size_t)(bx * blockDim.z + threadIdx.z) * g.C + c0) * (K * K) + ky * K;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -324,7 +326,7 @@ static int run_fwd_or_bwd_data(bool fwd, const void* in, const float* w, void* o
     const int spr = (g.W + STRIP - 1) / STRIP;
     const long long n_strips = (long long)g.B * g.H * spr;
     if (n_strips > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
-    dim3 block(cgb, pb), grid((unsigned)((n_strips + pb - 1) / pb), g.C / (cgb * VEC));
+    dim3 block(cgb, pb), grid(xcd_grid((unsigned)((n_strips + pb - 1) / pb)), g.C / (cgb * VEC));
     const size_t lds = (size_t)K * K * cgb * VEC * sizeof(float) + (stats ? (size_t)2 * pb * cgb * VEC * sizeof(float) : 0);
     if (fwd)
       hipLaunchKernelGGL((dwconv_strip_kernel<T, K, STRIP, false>), grid, block, lds, st, (const T*)in, w, (T*)out, stats, g, (int)n_strips, spr);
@@ -335,7 +337,7 @@ static int run_fwd_or_bwd_data(bool fwd, const void* in, const float* w, void* o
   }
   if (stats) return DFINE_E_UNSUPPORTED;  // the statistics epilogue exists in the stride-1 strip kernel only
   const long long n_pix = fwd ? (long long)g.B * g.OH * g.OW : (long long)g.B * g.H * g.W;
-  dim3 block(cgb, pb), grid((unsigned)((n_pix + pb - 1) / pb), g.C / (cgb * VEC));
+  dim3 block(cgb, pb), grid(xcd_grid((unsigned)((n_pix + pb - 1) / pb)), g.C / (cgb * VEC));
   const size_t lds = (size_t)K * K * cgb * VEC * sizeof(float);
   if (fwd)
     hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, S>), grid, block, lds, st, (const T*)in, w, (T*)out, g, (int)n_pix);
@@ -376,7 +378,7 @@ static int run_bwd_weight(const void* x, const void* dy, float* dw, float* ws, l
   if (int rc = plan_wrw<K>(&P, g)) return rc;
   const long long n_out = (long long)g.C * K * K;
   if (!ws || ws_floats < P.parts * n_out) return DFINE_E_BADARG;
-  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, S>), P.grid, P.block, 0, st, (const T*)x, (const T*)dy, ws, g,
+  hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, S>), dim3(xcd_grid(P.grid.x), P.grid.y), P.block, 0, st, (const T*)x, (const T*)dy, ws, g,
                      g.B * g.OH, P.rpt);
   DFINE_LAUNCH_CHECK();
   const int chunks = P.parts >= 256 ? 64 : P.parts >= 64 ? 16 : 1;

@@ -7,6 +7,8 @@
 // Both kernels are HBM/L2-gather bound (no contraction worth an MFMA): the forward moves
 // Lq*nH*P*4 corner segments of c elements per image, the backward the same reads plus the
 // same number of float-atomic segments into grad_value.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dfine {
@@ -108,6 +110,66 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const T* __restrict__ val
     }
   }
   *reinterpret_cast<Vec16*>(out + (size_t)pair * C + sub * VEC) = VecTraits<T>::pack(acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward w.r.t. the sampling locations and attention weights ONLY (the value gradient is formed by the sorted gather below):
+// the forward's mapping -- C/VEC lanes per (batch, query, head), every corner one 16-byte load per lane -- with three dot
+// products over the head's channels per point (sampled value, d/dx, d/dy against grad_out), finished by a shuffle tree over the
+// pair's C/VEC lanes. The one-lane-per-channel form below needs C lanes, 2-byte loads and a 5-level tree for the same numbers:
+// 200 us per decoder layer against this kernel's time in tools/time_msda_value.py.
+// ------------------------------------------------------------------------------------------
+template <typename T, int C>
+__global__ __launch_bounds__(256) void msda_bwd_points_kernel(const T* __restrict__ value, const float* __restrict__ loc,
+                                                             const float* __restrict__ attn, const T* __restrict__ grad_out,
+                                                             float* __restrict__ grad_loc, float* __restrict__ grad_attn, MsdaGeom g,
+                                                             int n_pairs, int S, int Lq, int nH) {
+  constexpr int VEC = VecTraits<T>::kElems;
+  constexpr int LPP = C / VEC;  // lanes per pair
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pair = tid / LPP;
+  const bool live = pair < n_pairs;  // the host pads the grid to whole waves: dead lanes still take part in the shuffles
+  const int spair = live ? pair : 0;
+  const int sub = tid % LPP;
+  const int h = spair % nH;
+  const int b = spair / (nH * Lq);
+  const int row_stride = nH * C;
+  const T* vbase = value + ((size_t)b * S * nH + h) * C + sub * VEC;
+  const float* lp = loc + (size_t)spair * g.P * 2;
+  const float* ap = attn + (size_t)spair * g.P;
+  float go[VEC];
+  VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(grad_out + (size_t)spair * C + sub * VEC), go);
+
+  for (int l = 0; l < g.n_levels; ++l) {
+    const int H = g.H[l], W = g.W[l], start = g.start[l];
+#pragma unroll 3
+    for (int p = g.pt_begin[l]; p < g.pt_begin[l + 1]; ++p) {
+      const float2 xy = *reinterpret_cast<const float2*>(lp + 2 * p);
+      const float a = ap[p];
+      const Corners k = make_corners(xy.x, xy.y, H, W, start);
+      float v00[VEC], v01[VEC], v10[VEC], v11[VEC];
+      VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(vbase + (size_t)k.r00 * row_stride), v00);
+      VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(vbase + (size_t)k.r01 * row_stride), v01);
+      VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(vbase + (size_t)k.r10 * row_stride), v10);
+      VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(vbase + (size_t)k.r11 * row_stride), v11);
+      // corners outside the map read a clamped (valid) row and count as zero
+      const float m00 = (k.vx0 && k.vy0) ? 1.f : 0.f, m01 = (k.vx1 && k.vy0) ? 1.f : 0.f;
+      const float m10 = (k.vx0 && k.vy1) ? 1.f : 0.f, m11 = (k.vx1 && k.vy1) ? 1.f : 0.f;
+      float s_v = 0.f, s_x = 0.f, s_y = 0.f;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const float a00 = m00 * v00[i], a01 = m01 * v01[i], a10 = m10 * v10[i], a11 = m11 * v11[i];
+        s_v += go[i] * (k.w00 * a00 + k.w01 * a01 + k.w10 * a10 + k.w11 * a11);
+        s_x += go[i] * ((a01 - a00) * (1.0f - k.fy) + (a11 - a10) * k.fy);
+        s_y += go[i] * ((a10 - a00) * (1.0f - k.fx) + (a11 - a01) * k.fx);
+      }
+      s_v = group_sum<LPP>(s_v), s_x = group_sum<LPP>(s_x), s_y = group_sum<LPP>(s_y);
+      if (live && sub == 0) {
+        grad_attn[(size_t)pair * g.P + p] = s_v;
+        *reinterpret_cast<float2*>(grad_loc + ((size_t)pair * g.P + p) * 2) = make_float2(s_x * a * (float)W, s_y * a * (float)H);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -395,6 +457,19 @@ static int launch_bwd_value(const MsdaCalls& calls, float* grad_value, const Msd
   return 0;
 }
 
+template <typename T, int C>
+static int launch_bwd_points(const void* value, const float* loc, const float* attn, const void* grad_out, float* grad_loc, float* grad_attn,
+                             const MsdaGeom& g, int B, int S, int Lq, int nH, hipStream_t st) {
+  constexpr int LPP = C / VecTraits<T>::kElems;
+  const long long n_pairs = (long long)B * Lq * nH;
+  const long long grid = (n_pairs * LPP + 255) / 256;
+  if (grid > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
+  hipLaunchKernelGGL((msda_bwd_points_kernel<T, C>), dim3((unsigned)grid), dim3(256), 0, st, (const T*)value, loc, attn, (const T*)grad_out,
+                     grad_loc, grad_attn, g, (int)n_pairs, S, Lq, nH);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T, int C, bool SCATTER = true, bool PK = false>
 static int launch_bwd(const void* value, const float* loc, const float* attn,
                       const void* grad_out, void* grad_value, float* grad_loc, float* grad_attn,
@@ -409,6 +484,199 @@ static int launch_bwd(const void* value, const float* loc, const float* attn,
                      grad_attn, g, (int)n_pairs, S, Lq, nH);
   DFINE_LAUNCH_CHECK();
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// d(loss)/d(value) as a GATHER over per-token lists ("sorted"), for every deformable-attention call that sampled the same value
+// tensor, with no float atomics. The scatter above is bound by the chip's atomic rate: every (query, head, point, corner) adds
+// c = 32 channels, 193 M float adds per decoder layer. The ADDRESSES are shared by the 32 channels -- there are only 6 M
+// (token, head) hits per layer -- so the hits are counting-sorted by destination and each destination's list is summed in
+// registers from the grad_out rows (8 MB per call: L2 resident), every element of grad_value written exactly once. A first
+// version sorted with GLOBAL integer atomics (one counter per (token, head)): the L2 serves one atomic per cache LINE per
+// operation, and 64 lanes with 64 different counters are 64 line operations where the float scatter's 64 lanes cover two --
+// count 0.83 ms + fill 1.11 ms per backward pass of D-FINE-m at batch 32, against 2.5 ms for the whole float scatter. The hits of
+// one (image, head) only ever land on that (image, head)'s S tokens, so ONE workgroup per (image, head[, token range]) sorts
+// next to its own LDS:
+//   count   its calls' (query, point, corner) hits into an LDS histogram over its tokens (LDS integer atomics)
+//   scan    the histogram in LDS (offsets stay in LDS)
+//   fill    8-byte records {call | query, coefficient} into the workgroup's own segment of the record buffer
+//   gather  one half-wave (c lanes) per token: the list's records are read 32 at a time (one coalesced load, then lane
+//           broadcasts), every record's grad_out row is an independent load, the sum stays in registers, the token's
+//           gradient is written once
+// grad_value is WRITTEN (every element once). The record buffer needs n_calls * Lq * P * 4 records per workgroup.
+// ------------------------------------------------------------------------------------------
+constexpr int MSDA_SORT_THREADS = 1024;
+constexpr int MSDA_SORT_MAX_TOKENS = 16384;  // tokens per workgroup: 2 LDS int arrays of this size = 128 KB
+
+template <typename T, int C>
+__global__ __launch_bounds__(MSDA_SORT_THREADS) void msda_bwd_value_sorted_kernel(MsdaCalls calls, float* __restrict__ grad_value,
+                                                                                 uint2* __restrict__ entries, long long seg_cap, MsdaGeom g,
+                                                                                 int S, int Lq, int nH, int splits, int tok_per_split, int dbg) {
+  extern __shared__ int smem[];
+  int* const cur = smem;                     // [tok_per_split + 1] histogram -> running cursors
+  int* const off = smem + tok_per_split + 1;  // [tok_per_split + 1] list offsets
+  __shared__ const T* go_tab[MSDA_MAX_CALLS];
+  __shared__ int wave_tot[MSDA_SORT_THREADS / 64];
+  const int tid = threadIdx.x;
+  const int part = blockIdx.x % splits, bh = blockIdx.x / splits, b = bh / nH, h = bh % nH;
+  const int lo = part * tok_per_split, hi = min(lo + tok_per_split, S), n_tok = hi - lo;
+  uint2* const seg = entries + (size_t)blockIdx.x * seg_cap;
+  if (tid < MSDA_MAX_CALLS) go_tab[tid] = static_cast<const T*>(calls.grad_out[tid]);
+  for (int i = tid; i <= tok_per_split; i += MSDA_SORT_THREADS) cur[i] = 0;
+  __syncthreads();
+
+  const int n_pts = calls.n * Lq * g.P;  // (call, query, point) of this (image, head)
+  auto for_hits = [&](auto&& f) {
+    for (int i = tid; i < n_pts; i += MSDA_SORT_THREADS) {
+      const int p = i % g.P, rest = i / g.P;
+      const int q = rest % Lq, call = rest / Lq;
+      int l = 0;
+      while (l + 1 < g.n_levels && p >= g.pt_begin[l + 1]) ++l;
+      const float* lp = nullptr;
+      const float* ap = nullptr;
+#pragma unroll
+      for (int c = 0; c < MSDA_MAX_CALLS; ++c)
+        if (c == call) lp = calls.loc[c], ap = calls.attn[c];
+      const size_t pt = (((size_t)b * Lq + q) * nH + h) * g.P + p;
+      const float2 xy = *reinterpret_cast<const float2*>(lp + pt * 2);
+      const float a = ap[pt];
+      const Corners k = make_corners(xy.x, xy.y, g.H[l], g.W[l], g.start[l]);
+      const bool ok[4] = {k.vx0 && k.vy0, k.vx1 && k.vy0, k.vx0 && k.vy1, k.vx1 && k.vy1};
+      const int row[4] = {k.r00, k.r01, k.r10, k.r11};
+      const float w[4] = {k.w00, k.w01, k.w10, k.w11};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (ok[c] && row[c] >= lo && row[c] < hi) f(row[c] - lo, ((unsigned)call << 28) | (unsigned)q, a * w[c]);
+    }
+  };
+  // ---- count
+  for_hits([&](int t, unsigned, float) { atomicAdd(cur + t, 1); });
+  __syncthreads();
+  // ---- exclusive scan of cur[0 .. n_tok) -> off[], cur[] (thread t owns a contiguous run of tokens)
+  {
+    const int per = (n_tok + MSDA_SORT_THREADS - 1) / MSDA_SORT_THREADS;
+    const int t0 = min(tid * per, n_tok), t1 = min(t0 + per, n_tok);
+    int tot = 0;
+    for (int t = t0; t < t1; ++t) tot += cur[t];
+    int incl = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if ((tid & 63) >= d) incl += o;
+    }
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+    __syncthreads();
+    int run = incl - tot;
+    for (int w = 0; w < (tid >> 6); ++w) run += wave_tot[w];
+    for (int t = t0; t < t1; ++t) {
+      const int c = cur[t];
+      off[t] = run, cur[t] = run;
+      run += c;
+    }
+    if (t0 < n_tok && t1 == n_tok) off[n_tok] = run;  // the owner of the last token publishes the total
+    if (n_tok == 0 && tid == 0) off[0] = 0;
+  }
+  __syncthreads();
+  if (dbg == 1) return;  // diagnostics (tools/time_msda_value.py): count + scan only
+  // ---- fill
+  for_hits([&](int t, unsigned src, float coef) {
+    const int slot = atomicAdd(cur + t, 1);
+    if (slot < seg_cap) seg[slot] = make_uint2(src, __float_as_uint(coef));
+  });
+  __syncthreads();  // (also orders this workgroup's record stores before its own loads of them)
+  if (dbg == 2) return;  // diagnostics: no gather
+  // ---- gather: C/4 lanes per token, 4 channels per lane (8-byte bf16 / 16-byte f32 row pieces): with 32 single-channel lanes
+  // per token a workgroup had 32 tokens in flight and the phase was one L2 round trip per token long (0.95 of the kernel's
+  // 1.2 ms, tools/time_msda_value.py); 8 lanes per token put 128 tokens in flight
+  constexpr int LPT = C / 4, GROUPS = MSDA_SORT_THREADS / LPT;
+  const int grp = tid / LPT, sub = tid % LPT;
+  const size_t go_row = ((size_t)b * Lq * nH + h) * C + sub * 4;  // + query * nH * C
+  auto row4 = [&](unsigned src, float (&v)[4]) {
+    const T* p = go_tab[src >> 28] + go_row + (size_t)(src & 0x0fffffffu) * nH * C;
+    if (sizeof(T) == 2) {
+      const uint2 q = *reinterpret_cast<const uint2*>(p);
+      v[0] = __uint_as_float(q.x << 16), v[1] = __uint_as_float(q.x & 0xffff0000u);
+      v[2] = __uint_as_float(q.y << 16), v[3] = __uint_as_float(q.y & 0xffff0000u);
+    } else {
+      const float4 q = *reinterpret_cast<const float4*>(p);
+      v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+    }
+  };
+  for (int t = grp; t < n_tok; t += GROUPS) {
+    const int beg = off[t];
+    int end = off[t + 1];
+    if (end > seg_cap) end = (int)seg_cap;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = beg; j0 < end; j0 += 2 * LPT) {  // two record chunks per trip: a long list (a token many queries sit on) is a chain of trips
+      uint2 e0 = make_uint2(0u, 0u), e1 = make_uint2(0u, 0u);  // a zero record adds 0 * row(call 0, query 0): keeps the loop branch-free
+      if (j0 + sub < end) e0 = seg[j0 + sub];
+      if (j0 + LPT + sub < end) e1 = seg[j0 + LPT + sub];
+      const bool second = j0 + LPT < end;
+#pragma unroll
+      for (int j = 0; j < LPT; ++j) {
+        const unsigned src = __shfl(e0.x, j, LPT);
+        const float coef = __uint_as_float(__shfl(e0.y, j, LPT));
+        float v[4];
+        row4(src, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += coef * v[i];
+      }
+      if (second) {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+          const unsigned src = __shfl(e1.x, j, LPT);
+          const float coef = __uint_as_float(__shfl(e1.y, j, LPT));
+          float v[4];
+          row4(src, v);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] += coef * v[i];
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(grad_value + (((size_t)b * S + lo + t) * nH + h) * C + sub * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
+// token ranges per (image, head): enough workgroups to fill the chip (DFINE_MSDA_SORT_WGS, read per call, for measurements)
+static int sorted_splits(long long bh, int S) {
+  const char* e = getenv("DFINE_MSDA_SORT_WGS");
+  const long long want = e ? atoll(e) : 256;
+  int splits = 1;
+  while (bh * splits < want && splits < 64) splits <<= 1;
+  while ((S + splits - 1) / splits > MSDA_SORT_MAX_TOKENS) splits <<= 1;
+  return splits;
+}
+
+template <typename T, int C>
+static int launch_bwd_value_sorted(const MsdaCalls& calls, float* grad_value, uint2* entries, long long cap, const MsdaGeom& g,
+                                   int B, int S, int Lq, int nH, hipStream_t st) {
+  if (Lq >= (1 << 28)) return DFINE_E_UNSUPPORTED;
+  const long long bh = (long long)B * nH;
+  const int splits = sorted_splits(bh, S);
+  const int tok_per_split = (S + splits - 1) / splits;
+  const long long seg_cap = (long long)calls.n * Lq * g.P * 4;  // every hit of an (image, head) may fall into one range
+  const long long blocks = bh * splits;
+  if (blocks > 0x7fffffffLL || seg_cap > 0x7fffffffLL) return DFINE_E_UNSUPPORTED;
+  if (blocks * seg_cap > cap) return DFINE_E_BADARG;
+  const size_t lds = (size_t)2 * (tok_per_split + 1) * sizeof(int);
+  static bool attr_set[2][2] = {};
+  bool& done = attr_set[sizeof(T) == 2][C == 32];
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_bwd_value_sorted_kernel<T, C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * (MSDA_SORT_MAX_TOKENS + 1) * (int)sizeof(int)) != hipSuccess)
+      return DFINE_E_UNSUPPORTED;
+    done = true;
+  }
+  hipLaunchKernelGGL((msda_bwd_value_sorted_kernel<T, C>), dim3((unsigned)blocks), dim3(MSDA_SORT_THREADS), lds, st, calls, grad_value, entries,
+                     seg_cap, g, S, Lq, nH, splits, tok_per_split, getenv("DFINE_MSDA_SORT_DEBUG") ? atoi(getenv("DFINE_MSDA_SORT_DEBUG")) : 0);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
+// records dfine_msda_bwd_value_sorted needs for this geometry (host helper behind dfine_msda_sorted_records)
+static long long sorted_records(int n_calls, int B, int S, int Lq, int nH, int P) {
+  const long long bh = (long long)B * nH;
+  return bh * sorted_splits(bh, S) * ((long long)n_calls * Lq * P * 4);
 }
 
 // The glue in front of the gather (reference dfine_decoder.py:148-166): sampling locations from the offset projection and the
@@ -637,14 +905,10 @@ extern "C" int dfine_msda_bwd_points(const void* value, int value_dtype, const f
   MsdaGeom g;
   if (int rc = make_geom(&g, S, n_levels, level_hw, num_points)) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (value_dtype == DFINE_DT_BF16 && c == 32)
-    return launch_bwd<bf16_t, 32, false>(value, loc, attn, grad_out, nullptr, grad_loc, grad_attn, g, B, S, Lq, nH, st);
-  if (value_dtype == DFINE_DT_BF16 && c == 16)
-    return launch_bwd<bf16_t, 16, false>(value, loc, attn, grad_out, nullptr, grad_loc, grad_attn, g, B, S, Lq, nH, st);
-  if (value_dtype == DFINE_DT_F32 && c == 32)
-    return launch_bwd<float, 32, false>(value, loc, attn, grad_out, nullptr, grad_loc, grad_attn, g, B, S, Lq, nH, st);
-  if (value_dtype == DFINE_DT_F32 && c == 16)
-    return launch_bwd<float, 16, false>(value, loc, attn, grad_out, nullptr, grad_loc, grad_attn, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_BF16 && c == 32) return launch_bwd_points<bf16_t, 32>(value, loc, attn, grad_out, grad_loc, grad_attn, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_BF16 && c == 16) return launch_bwd_points<bf16_t, 16>(value, loc, attn, grad_out, grad_loc, grad_attn, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_F32 && c == 32) return launch_bwd_points<float, 32>(value, loc, attn, grad_out, grad_loc, grad_attn, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_F32 && c == 16) return launch_bwd_points<float, 16>(value, loc, attn, grad_out, grad_loc, grad_attn, g, B, S, Lq, nH, st);
   return DFINE_E_UNSUPPORTED;
 }
 
@@ -667,5 +931,34 @@ extern "C" int dfine_msda_bwd_value(int value_dtype, const void* const* loc, con
   if (value_dtype == DFINE_DT_BF16 && c == 16) return launch_bwd_value<bf16_t, 16>(calls, grad_value, g, B, S, Lq, nH, st);
   if (value_dtype == DFINE_DT_F32 && c == 32) return launch_bwd_value<float, 32>(calls, grad_value, g, B, S, Lq, nH, st);
   if (value_dtype == DFINE_DT_F32 && c == 16) return launch_bwd_value<float, 16>(calls, grad_value, g, B, S, Lq, nH, st);
+  return DFINE_E_UNSUPPORTED;
+}
+
+extern "C" long long dfine_msda_sorted_records(int n_calls, int B, int S, int Lq, int nH, int P) {
+  if (n_calls <= 0 || B <= 0 || S <= 0 || Lq <= 0 || nH <= 0 || P <= 0) return DFINE_E_BADARG;
+  return sorted_records(n_calls, B, S, Lq, nH, P);
+}
+
+extern "C" int dfine_msda_bwd_value_sorted(int value_dtype, const void* const* loc, const void* const* attn, const void* const* grad_out,
+                                           int n_calls, float* grad_value, void* entries, long long entries_cap, int B, int S, int Lq,
+                                           int nH, int c, int n_levels, const int32_t* level_hw, const int32_t* num_points, void* stream) {
+  if (!loc || !attn || !grad_out || !grad_value || !entries || !level_hw || !num_points) return DFINE_E_BADARG;
+  if (n_calls <= 0 || B <= 0 || S <= 0 || Lq <= 0 || nH <= 0 || entries_cap <= 0) return DFINE_E_BADARG;
+  if (n_calls > MSDA_MAX_CALLS) return DFINE_E_UNSUPPORTED;
+  MsdaGeom g;
+  if (int rc = make_geom(&g, S, n_levels, level_hw, num_points)) return rc;
+  MsdaCalls calls;
+  calls.n = n_calls;
+  for (int i = 0; i < MSDA_MAX_CALLS; ++i) {
+    if (i < n_calls && (!loc[i] || !attn[i] || !grad_out[i])) return DFINE_E_BADARG;
+    const int j = i < n_calls ? i : 0;  // unused slots alias call 0: every table entry is a valid pointer
+    calls.loc[i] = (const float*)loc[j], calls.attn[i] = (const float*)attn[j], calls.grad_out[i] = grad_out[j];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  uint2* en = static_cast<uint2*>(entries);
+  if (value_dtype == DFINE_DT_BF16 && c == 32) return launch_bwd_value_sorted<bf16_t, 32>(calls, grad_value, en, entries_cap, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_BF16 && c == 16) return launch_bwd_value_sorted<bf16_t, 16>(calls, grad_value, en, entries_cap, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_F32 && c == 32) return launch_bwd_value_sorted<float, 32>(calls, grad_value, en, entries_cap, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_F32 && c == 16) return launch_bwd_value_sorted<float, 16>(calls, grad_value, en, entries_cap, g, B, S, Lq, nH, st);
   return DFINE_E_UNSUPPORTED;
 }

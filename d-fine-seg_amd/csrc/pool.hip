@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* __restrict__ x, 
                                                        int C, int ldy) {
   constexpr int V = VecTraits<T>::kElems;
   const int cpp = C / V;  // chunks per pixel
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t t = (size_t)xcd_block_id() * blockDim.x + threadIdx.x;
   if (t >= (size_t)B * H * W * cpp) return;
   const int c0 = (int)(t % cpp) * V;
   size_t p = t / cpp;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, 
                                                        T* __restrict__ gx, int B, int H, int W, int C, int ld_gy) {
   constexpr int V = VecTraits<T>::kElems;
   const int cpp = C / V;
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t t = (size_t)xcd_block_id() * blockDim.x + threadIdx.x;
   if (t >= (size_t)B * H * W * cpp) return;
   const int c0 = (int)(t % cpp) * V;
   size_t p = t / cpp;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict
                                                             int ldy) {
   constexpr int V = VecTraits<T>::kElems;
   const int cpp = C / V;
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t t = (size_t)xcd_block_id() * blockDim.x + threadIdx.x;
   if (t >= (size_t)B * 2 * H * 2 * W * cpp) return;
   const int c0 = (int)(t % cpp) * V;
   size_t p = t / cpp;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict
                                                             int ld_gy) {
   constexpr int V = VecTraits<T>::kElems;
   const int cpp = C / V;
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t t = (size_t)xcd_block_id() * blockDim.x + threadIdx.x;
   if (t >= (size_t)B * H * W * cpp) return;
   const int c0 = (int)(t % cpp) * V;
   size_t p = t / cpp;
@@ -153,9 +153,9 @@ static int launch_upsample(bool fwd, const void* in, void* out, int B, int H, in
   if (ld % V != 0 || (uintptr_t)(fwd ? out : in) % (V * sizeof(T)) != 0) return DFINE_E_UNSUPPORTED;
   const size_t items = (size_t)B * H * W * (C / V) * (fwd ? 4 : 1);
   const size_t blocks = (items + 255) / 256;
-  if (blocks > 0x7fffffffULL) return DFINE_E_UNSUPPORTED;
-  if (fwd) hipLaunchKernelGGL(upsample2x_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)in, (T*)out, B, H, W, C, ld);
-  else hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)in, (T*)out, B, H, W, C, ld);
+  if (blocks > 0x7ffffff0ULL) return DFINE_E_UNSUPPORTED;
+  if (fwd) hipLaunchKernelGGL(upsample2x_fwd_kernel<T>, dim3(xcd_grid((unsigned)blocks)), dim3(256), 0, st, (const T*)in, (T*)out, B, H, W, C, ld);
+  else hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3(xcd_grid((unsigned)blocks)), dim3(256), 0, st, (const T*)in, (T*)out, B, H, W, C, ld);
   DFINE_LAUNCH_CHECK();
   return 0;
 }
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void bilinear_add_fwd_kernel(const T* __restri
                                                               int h, int w, int H, int W, int C, float sy, float sx) {
   constexpr int V = VecTraits<T>::kElems;
   const int cpp = C / V;
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t t = (size_t)xcd_block_id() * blockDim.x + threadIdx.x;
   if (t >= (size_t)B * H * W * cpp) return;
   const int c0 = (int)(t % cpp) * V;
   size_t p = t / cpp;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
                                                           int C, float sy, float sx) {
   constexpr int V = VecTraits<T>::kElems;
   const int cpp = C / V;
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t t = (size_t)xcd_block_id() * blockDim.x + threadIdx.x;
   if (t >= (size_t)B * h * w * cpp) return;
   const int c0 = (int)(t % cpp) * V;
   size_t p = t / cpp;
@@ -267,9 +267,9 @@ static int launch_bilinear(bool fwd, const void* in, const void* base, void* out
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
   const size_t items = (size_t)B * (fwd ? H : h) * (fwd ? W : w) * (C / V);
   const size_t blocks = (items + 255) / 256;
-  if (blocks > 0x7fffffffULL) return DFINE_E_UNSUPPORTED;
-  if (fwd) hipLaunchKernelGGL(bilinear_add_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)in, (const T*)base, (T*)out, B, h, w, H, W, C, sy, sx);
-  else hipLaunchKernelGGL(bilinear_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)in, (T*)out, B, h, w, H, W, C, sy, sx);
+  if (blocks > 0x7ffffff0ULL) return DFINE_E_UNSUPPORTED;
+  if (fwd) hipLaunchKernelGGL(bilinear_add_fwd_kernel<T>, dim3(xcd_grid((unsigned)blocks)), dim3(256), 0, st, (const T*)in, (const T*)base, (T*)out, B, h, w, H, W, C, sy, sx);
+  else hipLaunchKernelGGL(bilinear_bwd_kernel<T>, dim3(xcd_grid((unsigned)blocks)), dim3(256), 0, st, (const T*)in, (T*)out, B, h, w, H, W, C, sy, sx);
   DFINE_LAUNCH_CHECK();
   return 0;
 }
@@ -283,9 +283,9 @@ static int launch_pool(bool fwd, const void* x, const void* gy, void* out, int B
   if (ld < C || ld % V != 0 || (uintptr_t)(fwd ? out : gy) % (V * sizeof(T)) != 0) return ld < C ? DFINE_E_BADARG : DFINE_E_UNSUPPORTED;
   const size_t items = (size_t)B * H * W * (C / V);
   const size_t blocks = (items + 255) / 256;
-  if (blocks > 0x7fffffffULL) return DFINE_E_UNSUPPORTED;
-  if (fwd) hipLaunchKernelGGL(pool_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (T*)out, B, H, W, C, ld);
-  else hipLaunchKernelGGL(pool_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (const T*)gy, (T*)out, B, H, W, C, ld);
+  if (blocks > 0x7ffffff0ULL) return DFINE_E_UNSUPPORTED;
+  if (fwd) hipLaunchKernelGGL(pool_fwd_kernel<T>, dim3(xcd_grid((unsigned)blocks)), dim3(256), 0, st, (const T*)x, (T*)out, B, H, W, C, ld);
+  else hipLaunchKernelGGL(pool_bwd_kernel<T>, dim3(xcd_grid((unsigned)blocks)), dim3(256), 0, st, (const T*)x, (const T*)gy, (T*)out, B, H, W, C, ld);
   DFINE_LAUNCH_CHECK();
   return 0;
 }

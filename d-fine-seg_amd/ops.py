@@ -146,12 +146,17 @@ class _MSDeformAttnCore(torch.autograd.Function):
         return sink.flush().to(value.dtype), grad_loc, grad_attn, None, None, None, None
 
 
-# How d(loss)/d(value) of the deformable attention is formed: "atomic" = global float atomics inside the backward kernel
-# (default, faster on MI355X), "slab" = deferred, one dfine_msda_bwd_value launch over all calls (LDS slabs, no global atomics,
-# bitwise reproducible). DFINE_MSDA_VALUE=slab selects the latter.
+# How d(loss)/d(value) of the deformable attention is formed (DFINE_MSDA_VALUE):
+#   "sorted" (default)  deferred: every call's backward computes grad_loc / grad_attn only and parks (loc, attn, grad_out); one
+#                       dfine_msda_bwd_value_sorted launch per backward pass counting-sorts each (image, head)'s hits by token
+#                       in LDS and gathers -- no float atomics, every element written once
+#   "atomic"            global float atomics inside each call's backward kernel (193 M adds per layer: the chip's atomic rate)
+#   "slab"              deferred, LDS slabs with LDS float atomics (dfine_msda_bwd_value; bitwise reproducible, slowest)
 import os as _os
 
-MSDA_VALUE_GRAD = "slab" if _os.environ.get("DFINE_MSDA_VALUE", "") == "slab" else "atomic"
+MSDA_VALUE_GRAD = _os.environ.get("DFINE_MSDA_VALUE", "sorted")
+if MSDA_VALUE_GRAD not in ("atomic", "slab", "sorted"):
+    raise ValueError("DFINE_MSDA_VALUE must be atomic, slab or sorted")
 # "atomic" mode with bf16 values: float atomics into an fp32 map by default -- what the reference's AMP path does (grid_sample
 # is on autocast's fp32 list, so its backward accumulates in fp32). DFINE_MSDA_GRAD=bf16 selects PACKED bf16 atomics into a
 # bf16 map: half the atomic bytes (384 vs 630 us per layer at D-FINE-m batch 32) but the running sum is rounded to 8 bits at
@@ -194,6 +199,23 @@ class ValueGradSink:
         code = _lib.DT_BF16 if dtype == torch.bfloat16 else _lib.DT_F32
         P = sum(num_points)
         total = None
+        if MSDA_VALUE_GRAD == "sorted" and len(self.pending) <= 8:
+            n = len(self.pending)
+            arr = lambda k: (ctypes.c_void_p * n)(*[t[k].data_ptr() for t in self.pending])
+            total = torch.empty(B, S, nH, c, dtype=torch.float32, device=device)
+            cap = int(lib.dfine_msda_sorted_records(n, B, S, Lq, nH, P))
+            entries = torch.empty(cap, 2, dtype=torch.int32, device=device)
+            es = 2 if dtype == torch.bfloat16 else 4
+            hits = n * B * Lq * nH * P * 4  # bound: every corner inside its map
+            # bytes: points read twice (count, fill), one 8-byte record written and read per hit, a grad_out row per hit (from
+            # L2), the gradient written once
+            nbytes = 2 * n * B * Lq * nH * P * 12 + hits * (16 + c * es) + total.numel() * 4
+            with _lib.timed("msda_bwd_value", nbytes):
+                rc = lib.dfine_msda_bwd_value_sorted(code, arr(0), arr(1), arr(2), n, _lib.ptr(total), _lib.ptr(entries), cap, B, S, Lq, nH, c,
+                                                     len(num_points), hw, npts, _lib.stream_ptr())
+            _lib.check(rc, "dfine_msda_bwd_value_sorted")
+            self.pending, self.meta = [], None
+            return total
         for first in range(0, len(self.pending), 8):  # the kernel takes up to 8 calls per launch
             chunk = self.pending[first : first + 8]
             n = len(chunk)

@@ -57,12 +57,14 @@ def _run(fname, amp=True, msda_f32=False):
     if tb.masks is not None:
         s = t.model.decoder.spec.strides[0] // 2
         tb.dense_mask_targets(img // s, img // s, t.device)
-    old = ops.MSDA_GRAD_BF16
+    old, old_mode = ops.MSDA_GRAD_BF16, ops.MSDA_VALUE_GRAD
     ops.MSDA_GRAD_BF16 = not msda_f32
+    if not msda_f32:
+        ops.MSDA_VALUE_GRAD = "atomic"  # the packed-bf16 map exists in the scatter form only
     try:
         t._forward_backward(t._model_input(x), tb, inject)
     finally:
-        ops.MSDA_GRAD_BF16 = old
+        ops.MSDA_GRAD_BF16, ops.MSDA_VALUE_GRAD = old, old_mode
     torch.cuda.synchronize()
     for h in hooks:
         h.remove()

@@ -48,6 +48,13 @@ CONV_CASES = [
     (3, 13, 11, 160, 48, 1, 1, 0, None),    # M not a multiple of the tile
     (1, 30, 30, 192, 192, 3, 1, 1, None),   # x encoder 3x3
     (1, 8, 8, 32, 32, 3, 1, 1, None),
+    # more 3x3 stride-1 shapes: ragged right and bottom edges, N tails
+    (2, 80, 80, 96, 64, 3, 1, 1, None),     # HGNetv2 stage 2 first layer
+    (1, 160, 160, 32, 32, 3, 1, 1, None),   # HGNetv2 stage 1
+    (2, 40, 40, 128, 128, 3, 1, 1, None),
+    (3, 17, 23, 32, 48, 3, 1, 1, None),
+    (2, 21, 37, 64, 136, 3, 1, 1, None),
+    (1, 5, 3, 32, 32, 3, 1, 1, None),
 ]
 
 
@@ -175,14 +182,14 @@ def test_two_convs_of_one_input_form_one_input_gradient(hip_lib, monkeypatch):
         x = x.bfloat16().contiguous(memory_format=torch.channels_last)
         outs = []
         for m, paired in ((ref, False), (mod, True)):
-            if not paired:
-                monkeypatch.setattr(ConvNorm, "_pairable", lambda self, x: False)
-            xx = x.clone().requires_grad_(True)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                y = m(xx)
-            (y.float() * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
-            outs.append((y.detach(), xx.grad, {n: p.grad for n, p in m.named_parameters()}))
-            monkeypatch.undo()
+            with monkeypatch.context() as mp:  # (not monkeypatch.undo(): the igemm_body fixture's environment must stay)
+                if not paired:
+                    mp.setattr(ConvNorm, "_pairable", lambda self, x: False)
+                xx = x.clone().requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = m(xx)
+                (y.float() * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
+                outs.append((y.detach(), xx.grad, {n: p.grad for n, p in m.named_parameters()}))
         (y0, g0, p0), (y1, g1, p1) = outs
         assert torch.equal(y0, y1) and torch.equal(g0, g1)
         for n in p0:  # weight gradients are sums of float atomics (order varies run to run), the rest are plain reductions
