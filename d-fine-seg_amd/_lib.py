@@ -29,6 +29,7 @@ SIGNATURES = {
     "dfine_dwconv_bwd_weight_workspace": [_c_int] * 6,
     "dfine_bn_act_fwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 9 + [_c_int] * 4 + [ctypes.c_float] * 2 + [_c_int, _c_int, _c_void_p, _c_int, _c_void_p],
     "dfine_criterion_head": [_c_void_p, _c_int] + [_c_void_p] * 17 + [_c_int] * 5 + [ctypes.c_float] * 4 + [_c_void_p, _c_void_p],
+    "dfine_criterion_head_scale": [_c_void_p, _c_int] + [_c_void_p] * 12 + [ctypes.c_longlong] * 3 + [_c_void_p],
     "dfine_linear_wgrad": [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p],
     "dfine_conv_wgrad": [_c_void_p] * 3 + [_c_int] * 13 + [_c_void_p],
     "dfine_fdr_head_fwd": [_c_void_p] * 6 + [ctypes.c_longlong, _c_int, _c_int, ctypes.c_float, _c_void_p],
@@ -77,7 +78,7 @@ SIGNATURES = {
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int, _c_void_p, _c_int, _c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 _lib = None
 
 IGEMM_MAX_TAPS = 16

@@ -232,9 +232,64 @@ __global__ __launch_bounds__(256) void criterion_head_kernel(
   }
 }
 
+// Backward of a head's five weighted terms: the forward already holds d(term)/d(input); autograd hands five scalar
+// gradients (the five terms' d(loss)/d(term)) and the chain rule is
+//     d logits = d_logits * g_vfl     d boxes = d_l1 * g_l1 + d_giou * g_giou     d corners = d_fgl * g_fgl + d_ddf * g_ddf
+// -- five or six elementwise launches over small tensors as PyTorch ops, one here.
+template <typename T>
+__global__ __launch_bounds__(256) void criterion_scale_kernel(const T* __restrict__ d_logits, const float* __restrict__ d_l1,
+                                                              const float* __restrict__ d_giou, const float* __restrict__ d_fgl,
+                                                              const float* __restrict__ d_ddf, const float* __restrict__ g_vfl,
+                                                              const float* __restrict__ g_l1, const float* __restrict__ g_giou,
+                                                              const float* __restrict__ g_fgl, const float* __restrict__ g_ddf,
+                                                              T* __restrict__ o_logits, float* __restrict__ o_boxes,
+                                                              float* __restrict__ o_corners, long long n_logits, long long n_boxes,
+                                                              long long n_corners) {
+  // (the PyTorch form casts the scalar to the logits' dtype first)
+  const float sv = g_vfl ? (sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(g_vfl[0])) : g_vfl[0]) : 0.f;
+  const float s1 = g_l1 ? g_l1[0] : 0.f, s2 = g_giou ? g_giou[0] : 0.f;
+  const float s3 = g_fgl ? g_fgl[0] : 0.f, s4 = g_ddf ? g_ddf[0] : 0.f;
+  const long long total = n_logits + n_boxes + n_corners;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    if (i < n_logits) {
+      store1(o_logits + i, VecTraits<T>::load1(d_logits + i) * sv);
+    } else if (i < n_logits + n_boxes) {
+      const long long j = i - n_logits;
+      o_boxes[j] = d_l1[j] * s1 + d_giou[j] * s2;
+    } else {
+      const long long j = i - n_logits - n_boxes;
+      o_corners[j] = d_fgl[j] * s3 + (d_ddf ? d_ddf[j] * s4 : 0.f);
+    }
+  }
+}
+
 }  // namespace dfine
 
 using namespace dfine;
+
+extern "C" int dfine_criterion_head_scale(const void* d_logits, int logits_dtype, const float* d_boxes_l1, const float* d_boxes_giou,
+                                          const float* d_corners_fgl, const float* d_corners_ddf, const float* g_vfl, const float* g_l1,
+                                          const float* g_giou, const float* g_fgl, const float* g_ddf, void* out_logits, float* out_boxes,
+                                          float* out_corners, long long n_logits, long long n_boxes, long long n_corners, void* stream) {
+  if (!d_logits || !d_boxes_l1 || !d_boxes_giou || !out_logits || !out_boxes) return DFINE_E_BADARG;
+  if (n_logits <= 0 || n_boxes <= 0 || n_corners < 0 || (n_corners > 0 && (!d_corners_fgl || !out_corners))) return DFINE_E_BADARG;
+  const long long total = n_logits + n_boxes + n_corners;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (logits_dtype == DFINE_DT_F32)
+    hipLaunchKernelGGL(criterion_scale_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)d_logits, d_boxes_l1, d_boxes_giou,
+                       d_corners_fgl, d_corners_ddf, g_vfl, g_l1, g_giou, g_fgl, g_ddf, (float*)out_logits, out_boxes, out_corners, n_logits, n_boxes,
+                       n_corners);
+  else if (logits_dtype == DFINE_DT_BF16)
+    hipLaunchKernelGGL(criterion_scale_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)d_logits, d_boxes_l1, d_boxes_giou,
+                       d_corners_fgl, d_corners_ddf, g_vfl, g_l1, g_giou, g_fgl, g_ddf, (bf16_t*)out_logits, out_boxes, out_corners, n_logits,
+                       n_boxes, n_corners);
+  else
+    return DFINE_E_UNSUPPORTED;
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int dfine_criterion_head(const void* logits, int logits_dtype, const float* boxes, const float* corners,
                                     const float* ref_points, const float* teacher_corners, const void* teacher_logits,

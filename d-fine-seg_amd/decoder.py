@@ -404,8 +404,15 @@ class DFINETransformer(nn.Module):
             return res
 
         Nd = dn_meta["dn_num_split"][0]
-        dn_part = lambda t: t[:, :Nd]
-        reg_part = lambda t: t[:, Nd:]
+        parts = {}  # each output tensor is split ONCE (ops.split_rows: one autograd node, its backward one concatenation)
+
+        def _split(t):
+            if id(t) not in parts:
+                parts[id(t)] = (t, ops.split_rows(t, Nd))  # (the tensor is kept so that its id stays unique)
+            return parts[id(t)][1]
+
+        dn_part = lambda t: _split(t)[0]
+        reg_part = lambda t: _split(t)[1]
 
         def head(part, i, teacher, masks=None):
             d = {"pred_logits": part(logits_l[i]), "pred_boxes": part(boxes_l[i]), "pred_corners": part(corners_l[i]),

@@ -887,6 +887,38 @@ def batch_norm_act_supported(x, channels):
     return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
 
 
+class _SplitRows(torch.autograd.Function):
+    """(t[:, :n], t[:, n:]) of a [B, L, ...] tensor as ONE autograd node: the decoder hands the denoising and the matching part
+    of every head output to the criterion (reference dfine_decoder.py:1024-1050, torch.split on dn_num_split), and two
+    separate slices cost autograd a zero-filled full tensor + a copy each and an add of the two (5 launches per tensor, ~16
+    tensors per step); this node's backward is one concatenation."""
+
+    @staticmethod
+    def forward(ctx, t, n):
+        ctx.n, ctx.shape, ctx.meta = n, t.shape, (t.dtype, t.device)
+        ctx.set_materialize_grads(False)
+        return t[:, :n], t[:, n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        B, L = ctx.shape[0], ctx.shape[1]
+        rest = tuple(ctx.shape[2:])
+        if ga is None:
+            ga = torch.zeros((B, ctx.n) + rest, dtype=gb.dtype, device=gb.device)
+        if gb is None:
+            gb = torch.zeros((B, L - ctx.n) + rest, dtype=ga.dtype, device=ga.device)
+        return torch.cat([ga, gb.to(ga.dtype)], 1), None
+
+
+def split_rows(t, n):
+    """``(t[:, :n], t[:, n:])`` (views) whose gradients come back as one concatenation (see _SplitRows)."""
+    if not (torch.is_grad_enabled() and t.requires_grad):
+        return t[:, :n], t[:, n:]
+    return _SplitRows.apply(t, int(n))
+
+
 class _CriterionHead(torch.autograd.Function):
     """Weighted loss terms of one head + their gradients; see include/dfine_hip.h (dfine_criterion_head)."""
 
@@ -944,13 +976,15 @@ class _CriterionHead(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_vfl, g_l1, g_giou, g_fgl, g_ddf):
         d_logits, d_l1, d_giou, d_fgl, d_ddf = ctx.saved_tensors
-        grad_logits = d_logits * g_vfl.to(d_logits.dtype)
-        grad_boxes = torch.addcmul(d_l1 * g_l1, d_giou, g_giou)
-        grad_corners = None
-        if d_fgl is not None:
-            grad_corners = d_fgl * g_fgl
-            if d_ddf is not None:
-                grad_corners = torch.addcmul(grad_corners, d_ddf, g_ddf)
+        lib = _lib.load()
+        grad_logits, grad_boxes = torch.empty_like(d_logits), torch.empty_like(d_l1)
+        grad_corners = torch.empty_like(d_fgl) if d_fgl is not None else None
+        gs = [g.float().reshape(1) if g is not None else None for g in (g_vfl, g_l1, g_giou, g_fgl, g_ddf)]
+        rc = lib.dfine_criterion_head_scale(
+            _lib.ptr(d_logits), _lib.dtype_code(d_logits), _lib.ptr(d_l1), _lib.ptr(d_giou), _lib.ptr(d_fgl), _lib.ptr(d_ddf),
+            *[_lib.ptr(g) for g in gs], _lib.ptr(grad_logits), _lib.ptr(grad_boxes), _lib.ptr(grad_corners),
+            d_logits.numel(), d_l1.numel(), d_fgl.numel() if d_fgl is not None else 0, _lib.stream_ptr())
+        _lib.check(rc, "dfine_criterion_head_scale")
         return (grad_logits, grad_boxes, grad_corners) + (None,) * 13
 
 

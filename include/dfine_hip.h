@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 20
+#define DFINE_ABI_VERSION 21
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -269,6 +269,16 @@ int dfine_criterion_head(const void* logits, int logits_dtype, const float* boxe
                          void* d_logits, float* d_boxes_l1, float* d_boxes_giou, float* d_corners_fgl,
                          float* d_corners_ddf, int B, int Q, int C, int G, int n_bins, float alpha, float gamma,
                          float reg_scale, float temperature, const long long* batch_strides, void* stream);
+
+/* Backward of dfine_criterion_head's five terms (autograd of the weighted sums in DFINECriterion.forward,
+ * src/d_fine/dfine_criterion.py:560-580): given the five terms' upstream scalar gradients g_* (device f32 [1] each; NULL = 0),
+ *     out_logits = d_logits * g_vfl   out_boxes = d_boxes_l1 * g_l1 + d_boxes_giou * g_giou
+ *     out_corners = d_corners_fgl * g_fgl + d_corners_ddf * g_ddf      (n_corners = 0: no corners; d_corners_ddf may be NULL)
+ * in one launch (n_* = element counts; out_logits in the logits' dtype, g_vfl rounded to it first like the PyTorch product). */
+int dfine_criterion_head_scale(const void* d_logits, int logits_dtype, const float* d_boxes_l1, const float* d_boxes_giou,
+                               const float* d_corners_fgl, const float* d_corners_ddf, const float* g_vfl, const float* g_l1,
+                               const float* g_giou, const float* g_fgl, const float* g_ddf, void* out_logits, float* out_boxes,
+                               float* out_corners, long long n_logits, long long n_boxes, long long n_corners, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Weight/bias gradient of y = x @ W^T + b (autograd of F.linear / nn.Linear, used by every
