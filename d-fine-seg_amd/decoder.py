@@ -377,7 +377,10 @@ class DFINETransformer(nn.Module):
         ref_detach = torch.sigmoid(ref_unact)
         boxes_l, logits_l, corners_l, hs = [], [], [], []
         for i, layer in enumerate(self.decoder.layers):
-            pos = self.query_pos_head(ref_detach).clamp(-10, 10)
+            # clamp(-10, 10) of the reference (dfine_decoder.py:472) as hardtanh: the same forward, and ONE backward kernel
+            # where clamp's autograd runs five (ge, le, logical_and, where, fill); the two differ only in passing a gradient
+            # to an element that sits EXACTLY on +-10 (clamp does, hardtanh does not)
+            pos = F.hardtanh(self.query_pos_head(ref_detach), -10.0, 10.0)
             out = layer(out, ref_detach, value, spatial_shapes, blocked, pos, sink, finalize=False)  # select_rows finalizes
             hs.append(out)
             if i == 0:
