@@ -234,6 +234,37 @@ def test_train_step_ema_and_shadow_are_aligned_across_ranks_world2_gloo():
         assert dict(result) == {0: "ok", 1: "ok"}
 
 
+def _syncbn_worker(rank, world, port, result):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dfine_seg_amd import ops
+        from dfine_seg_amd.layers import ConvNorm, sync_group_of
+
+        # the conversion the reference applies under DDP with a per-GPU batch below 4 (src/dl/train.py:159-160) reaches the
+        # norm inside this repo's ConvNorm, parameters kept; the fused path then shares statistics over (default group, 2 ranks)
+        layer = nn.SyncBatchNorm.convert_sync_batchnorm(ConvNorm(4, 8, 3, act="relu"))
+        assert isinstance(layer.norm, nn.SyncBatchNorm) and sync_group_of(layer.norm) == (None, world)
+        assert sync_group_of(nn.SyncBatchNorm(8, process_group=dist.new_group([rank]))) is None  # one rank: nothing to share
+        # the fp64 sums of a norm workspace travel as their fp32 view: the average must be taken on the doubles
+        sums = torch.tensor([1.0 + rank, 1e-9 * (3 + rank), 12345.678 * (rank + 1)], dtype=torch.float64)
+        ws = sums.clone().view(torch.float32)
+        ops._average_over_ranks(ws, (None, world))
+        expect = torch.tensor([1.5, 3.5e-9, 12345.678 * 1.5], dtype=torch.float64)
+        torch.testing.assert_close(ws.view(torch.float64), expect, rtol=1e-15, atol=0)
+        result[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_batch_norm_group_and_fp64_sum_average_world2_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        result = mgr.dict()
+        mp.spawn(_syncbn_worker, args=(world, _free_port(), result), nprocs=world, join=True)
+        assert dict(result) == {0: "ok", 1: "ok"}
+
+
 def test_bucket_assignment_covers_every_trainable_parameter_once():
     model = Toy()
     buckets = assign_buckets(FlatState(model).entries, num_buckets=3, min_bucket_bytes=64)
