@@ -131,6 +131,159 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
   }
 }
 
+// bf16, D = 128 / 256: LPR = 16 lanes per row, FOUR rows per wave. A lane owns NCH chunks of 8 elements (chunk k of the row
+// at element (k * LPR + sub) * 8: every load / store instruction covers whole rows contiguously). One row per wave made the
+// 15 744-token launches of the decoder a chain of two 64-lane reductions per row with nothing else in flight (22 us backward
+// for 24 MB); four rows per wave run four such chains side by side, each 4 shuffle levels deep instead of 6.
+template <int LPR, int NCH>
+__global__ __launch_bounds__(256) void add_ln_fwd_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              bf16_t* __restrict__ y, bf16_t* __restrict__ s_out, float* __restrict__ mean_out,
+                                                              float* __restrict__ rstd_out, long long M, float eps, float clamp) {
+  constexpr int D = LPR * NCH * 8, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * 4;
+  float g[NCH][8], b[NCH][8];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[k][i] = gamma[(k * LPR + sub) * 8 + i], b[k][i] = beta[(k * LPR + sub) * 8 + i];
+  for (long long row0 = wave * RPW; row0 < M; row0 += n_waves * RPW) {
+    const long long row = row0 + rsel;
+    const bool live = row < M;
+    const long long r = live ? row : M - 1;  // dead row slots of the last wave recompute a valid row and store nothing
+    float v[NCH][8];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const long long o = r * D + (k * LPR + sub) * 8;
+      load_vec<bf16_t, 8>(x + o, v[k]);
+      if (res) {
+        float t[8];
+        load_vec<bf16_t, 8>(res + o, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[k][i] += t[i];
+      }
+      if (clamp > 0.f) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[k][i] = fminf(fmaxf(v[k][i], -clamp), clamp);
+      }
+      if (s_out) {  // the normalised quantity as the backward will read it (rounded to bf16)
+        if (live) store_vec<bf16_t, 8>(s_out + o, v[k]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[k][i] = round_to<bf16_t>(v[k][i]);
+      }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum += v[k][i];
+    const float mean = group_sum<LPR>(sum) * (1.f / D);
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) var += (v[k][i] - mean) * (v[k][i] - mean);
+    const float rstd = rsqrtf(group_sum<LPR>(var) * (1.f / D) + eps);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (v[k][i] - mean) * rstd * g[k][i] + b[k][i];
+      if (live) store_vec<bf16_t, 8>(y + r * D + (k * LPR + sub) * 8, o);
+    }
+    if (live && sub == 0) mean_out[row] = mean, rstd_out[row] = rstd;
+  }
+}
+
+template <int LPR, int NCH>
+__global__ __launch_bounds__(256) void add_ln_bwd_rows_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ s,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                              const float* __restrict__ rstd_in, bf16_t* __restrict__ ds,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, long long M, float clamp) {
+  constexpr int D = LPR * NCH * 8, RPW = 64 / LPR;
+  __shared__ float red[2][4][D];
+  const int lane = threadIdx.x & 63, sub = lane % LPR, rsel = lane / LPR, w = threadIdx.x >> 6;
+  const long long wave = (long long)blockIdx.x * 4 + w, n_waves = (long long)gridDim.x * 4;
+  float g[NCH][8], ag[NCH][8], ab[NCH][8];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[k][i] = gamma[(k * LPR + sub) * 8 + i], ag[k][i] = 0.f, ab[k][i] = 0.f;
+  for (long long row0 = wave * RPW; row0 < M; row0 += n_waves * RPW) {
+    const long long row = row0 + rsel;
+    const bool live = row < M;
+    const long long r = live ? row : M - 1;
+    const float mean = mean_in[r], rstd = rstd_in[r], keep = live ? 1.f : 0.f;
+    float d[NCH][8], v[NCH][8], xh[NCH][8];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const long long o = r * D + (k * LPR + sub) * 8;
+      load_vec<bf16_t, 8>(dy + o, d[k]);
+      load_vec<bf16_t, 8>(s + o, v[k]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        xh[k][i] = (v[k][i] - mean) * rstd;
+        const float dg = d[k][i] * g[k][i];
+        c1 += dg;
+        c2 += dg * xh[k][i];
+        ag[k][i] += keep * d[k][i] * xh[k][i];
+        ab[k][i] += keep * d[k][i];
+      }
+    }
+    c1 = group_sum<LPR>(c1) * (1.f / D);
+    c2 = group_sum<LPR>(c2) * (1.f / D);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        o[i] = rstd * (d[k][i] * g[k][i] - c1 - xh[k][i] * c2);
+        if (clamp > 0.f && (v[k][i] <= -clamp || v[k][i] >= clamp)) o[i] = 0.f;  // clamp's gradient (saturated: 0)
+      }
+      if (live) store_vec<bf16_t, 8>(ds + r * D + (k * LPR + sub) * 8, o);
+    }
+  }
+  // the wave's RPW row slots hold partial column sums of the same columns: fold them, then waves through LDS
+#pragma unroll
+  for (int k = 0; k < NCH; ++k)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int m = LPR; m < 64; m <<= 1) ag[k][i] += __shfl_xor(ag[k][i], m, 64), ab[k][i] += __shfl_xor(ab[k][i], m, 64);
+    }
+  if (rsel == 0) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red[0][w][(k * LPR + sub) * 8 + i] = ag[k][i], red[1][w][(k * LPR + sub) * 8 + i] = ab[k][i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
+template <int LPR, int NCH>
+static int launch_ln_rows(bool fwd, const void* a, const void* b, const float* gamma, const float* beta, void* out, void* s_out,
+                          float* mean, float* rstd, float* dgamma, float* dbeta, long long M, float eps, float clamp, hipStream_t st) {
+  constexpr int RPB = 4 * (64 / LPR);  // rows per workgroup and trip
+  long long blocks = (M + RPB - 1) / RPB;
+  static const int bwd_cap = getenv("DFINE_LN_BWD_BLOCKS") ? atoi(getenv("DFINE_LN_BWD_BLOCKS")) : 256;  // see launch_ln
+  const long long cap = fwd ? 2048 : bwd_cap;
+  if (blocks > cap) blocks = cap;
+  if (fwd)
+    hipLaunchKernelGGL((add_ln_fwd_rows_kernel<LPR, NCH>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, gamma,
+                       beta, (bf16_t*)out, (bf16_t*)s_out, mean, rstd, M, eps, clamp);
+  else
+    hipLaunchKernelGGL((add_ln_bwd_rows_kernel<LPR, NCH>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, gamma,
+                       mean, rstd, (bf16_t*)out, dgamma, dbeta, M, clamp);
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T, int E>
 static int launch_ln(bool fwd, const void* a, const void* b, const float* gamma, const float* beta, void* out, void* s_out,
                      float* mean, float* rstd, float* dgamma, float* dbeta, long long M, float eps, float clamp, hipStream_t st) {
@@ -203,6 +356,11 @@ __global__ __launch_bounds__(256) void gate_mix_bwd_kernel(const T* __restrict__
   }
 }
 
+static bool ln_rows_enabled() {  // DFINE_LN_ROWS=0: the one-row-per-wave kernels for every shape (A/B measurements), read per call
+  const char* e = getenv("DFINE_LN_ROWS");
+  return !(e && atoi(e) == 0);
+}
+
 }  // namespace dfine
 
 using namespace dfine;
@@ -248,6 +406,10 @@ extern "C" int dfine_add_layernorm_fwd(const void* x, const void* res, int dtype
   if (!x || !gamma || !beta || !y || !mean || !rstd) return DFINE_E_BADARG;
   if (M <= 0 || D <= 0 || eps <= 0.f) return DFINE_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == DFINE_DT_BF16 && ln_rows_enabled()) {  // four rows per wave (see add_ln_fwd_rows_kernel)
+    if (D == 256) return launch_ln_rows<16, 2>(true, x, res, gamma, beta, y, s_out, mean, rstd, nullptr, nullptr, M, eps, clamp, st);
+    if (D == 128) return launch_ln_rows<16, 1>(true, x, res, gamma, beta, y, s_out, mean, rstd, nullptr, nullptr, M, eps, clamp, st);
+  }
 #define FWD(T, E) launch_ln<T, E>(true, x, res, gamma, beta, y, s_out, mean, rstd, nullptr, nullptr, M, eps, clamp, st)
   DFINE_LN_DISPATCH(FWD);
 #undef FWD
@@ -259,6 +421,10 @@ extern "C" int dfine_add_layernorm_bwd(const void* dy, const void* s, int dtype,
   if (!dy || !s || !gamma || !mean || !rstd || !ds || !dgamma || !dbeta) return DFINE_E_BADARG;
   if (M <= 0 || D <= 0) return DFINE_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == DFINE_DT_BF16 && ln_rows_enabled()) {
+    if (D == 256) return launch_ln_rows<16, 2>(false, dy, s, gamma, nullptr, ds, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dgamma, dbeta, M, 0.f, clamp, st);
+    if (D == 128) return launch_ln_rows<16, 1>(false, dy, s, gamma, nullptr, ds, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dgamma, dbeta, M, 0.f, clamp, st);
+  }
 #define BWD(T, E) launch_ln<T, E>(false, dy, s, gamma, nullptr, ds, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), dgamma, dbeta, M, 0.f, clamp, st)
   DFINE_LN_DISPATCH(BWD);
 #undef BWD
