@@ -137,6 +137,18 @@ def spawn_ranks(n_ranks):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     worker = os.environ.get("DFINE_BENCH_WORKER", os.path.abspath(__file__))
+    if "DFINE_BENCH_WORKER" not in os.environ:  # compile once here (hipcc only, no GPU call) instead of N ranks queueing on the build lock
+        import __graft_entry__
+
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)  # whatever a compile prints goes to stderr: stdout carries rank 0's JSON line and nothing else
+        try:
+            __graft_entry__.build()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     procs = []
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),

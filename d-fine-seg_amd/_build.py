@@ -64,9 +64,25 @@ def build(force=False, verbose=False):
     source (only the stale ones, in parallel), then one link."""
     if not force and not _stale():
         return LIB_PATH
-    from concurrent.futures import ThreadPoolExecutor
+    import fcntl
 
     os.makedirs(os.path.join(CSRC_DIR, "build"), exist_ok=True)
+    # one builder at a time: the N ranks of `bench.py --gpus N` / torchrun all come through here at once, and two hipcc runs
+    # writing the same objects / the same .so would hand a third rank a half-written library. The others wait, then find it fresh
+    lock = open(os.path.join(CSRC_DIR, "build", ".lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and not _stale():
+            return LIB_PATH
+        return _build_locked(force, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(force, verbose):
+    from concurrent.futures import ThreadPoolExecutor
+
     headers = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith(".h")]
     headers += [os.path.join(INCLUDE_DIR, f) for f in os.listdir(INCLUDE_DIR)]
     newest_header = max(os.path.getmtime(h) for h in headers)
@@ -79,10 +95,12 @@ def build(force=False, verbose=False):
         for src, rc, log in pool.map(_compile_one, jobs):
             if rc != 0:
                 raise RuntimeError(f"hipcc failed on {src} ({rc}):\n{log}")
-    cmd = [find_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *[_object_path(s) for s in sources()]]
+    tmp = LIB_PATH + f".tmp{os.getpid()}"
+    cmd = [find_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *[_object_path(s) for s in sources()]]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError(f"hipcc link failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+    os.replace(tmp, LIB_PATH)  # atomic: a process loading the library never sees a half-written file
     return LIB_PATH

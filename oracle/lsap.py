@@ -13,8 +13,17 @@ _lib = None
 
 def build():
     src = os.path.join(_DIR, "lsap.c")
-    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", _DIR, "-s"], check=True)
+    stale = lambda: not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src)
+    if stale():
+        import fcntl
+
+        with open(os.path.join(_DIR, ".build.lock"), "w") as lock:  # the N ranks of a multi-GPU bench all pass through build()
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if stale():
+                    subprocess.run(["make", "-C", _DIR, "-s"], check=True)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return _SO
 
 
