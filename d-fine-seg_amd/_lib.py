@@ -53,7 +53,7 @@ SIGNATURES = {
     "dfine_igemm_bf16_bnred": [_c_void_p] * 6,
     "dfine_msda_bwd_points": [_c_void_p, _c_int] + [_c_void_p] * 5 + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
     "dfine_msda_bwd_value": [_c_int] + [ctypes.POINTER(_c_void_p)] * 3 + [_c_int, _c_void_p] + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
-    "dfine_msda_bwd_value_sorted": [_c_int] + [ctypes.POINTER(_c_void_p)] * 3 + [_c_int, _c_void_p, _c_void_p, ctypes.c_longlong]
+    "dfine_msda_bwd_value_sorted": [_c_int] + [ctypes.POINTER(_c_void_p)] * 3 + [_c_int, _c_void_p, _c_int, _c_void_p, ctypes.c_longlong]
                                    + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
     "dfine_msda_sorted_records": [_c_int] * 6,
     "dfine_mask_targets_nearest": [_c_void_p, _c_void_p, ctypes.c_longlong] + [_c_int] * 6 + [_c_void_p],
@@ -78,7 +78,7 @@ SIGNATURES = {
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int, _c_void_p, _c_int, _c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 _lib = None
 
 IGEMM_MAX_TAPS = 16

@@ -509,7 +509,7 @@ constexpr int MSDA_SORT_THREADS = 1024;
 constexpr int MSDA_SORT_MAX_TOKENS = 16384;  // tokens per workgroup: 2 LDS int arrays of this size = 128 KB
 
 template <typename T, int C>
-__global__ __launch_bounds__(MSDA_SORT_THREADS) void msda_bwd_value_sorted_kernel(MsdaCalls calls, float* __restrict__ grad_value,
+__global__ __launch_bounds__(MSDA_SORT_THREADS) void msda_bwd_value_sorted_kernel(MsdaCalls calls, void* __restrict__ grad_value, int out_bf16,
                                                                                  uint2* __restrict__ entries, long long seg_cap, MsdaGeom g,
                                                                                  int S, int Lq, int nH, int splits, int tok_per_split, int dbg) {
   extern __shared__ int smem[];
@@ -633,7 +633,15 @@ __global__ __launch_bounds__(MSDA_SORT_THREADS) void msda_bwd_value_sorted_kerne
         }
       }
     }
-    *reinterpret_cast<float4*>(grad_value + (((size_t)b * S + lo + t) * nH + h) * C + sub * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    const size_t o = (((size_t)b * S + lo + t) * nH + h) * C + sub * 4;
+    if (out_bf16) {  // the sum is formed in fp32 registers either way; a bf16 map saves the caller's conversion pass
+      uint2 pk;
+      pk.x = (uint32_t)f32_to_bf16(acc[0]) | ((uint32_t)f32_to_bf16(acc[1]) << 16);
+      pk.y = (uint32_t)f32_to_bf16(acc[2]) | ((uint32_t)f32_to_bf16(acc[3]) << 16);
+      *reinterpret_cast<uint2*>(static_cast<bf16_t*>(grad_value) + o) = pk;
+    } else {
+      *reinterpret_cast<float4*>(static_cast<float*>(grad_value) + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
   }
 }
 
@@ -648,7 +656,7 @@ static int sorted_splits(long long bh, int S) {
 }
 
 template <typename T, int C>
-static int launch_bwd_value_sorted(const MsdaCalls& calls, float* grad_value, uint2* entries, long long cap, const MsdaGeom& g,
+static int launch_bwd_value_sorted(const MsdaCalls& calls, void* grad_value, int out_bf16, uint2* entries, long long cap, const MsdaGeom& g,
                                    int B, int S, int Lq, int nH, hipStream_t st) {
   if (Lq >= (1 << 28)) return DFINE_E_UNSUPPORTED;
   const long long bh = (long long)B * nH;
@@ -667,7 +675,7 @@ static int launch_bwd_value_sorted(const MsdaCalls& calls, float* grad_value, ui
       return DFINE_E_UNSUPPORTED;
     done = true;
   }
-  hipLaunchKernelGGL((msda_bwd_value_sorted_kernel<T, C>), dim3((unsigned)blocks), dim3(MSDA_SORT_THREADS), lds, st, calls, grad_value, entries,
+  hipLaunchKernelGGL((msda_bwd_value_sorted_kernel<T, C>), dim3((unsigned)blocks), dim3(MSDA_SORT_THREADS), lds, st, calls, grad_value, out_bf16, entries,
                      seg_cap, g, S, Lq, nH, splits, tok_per_split, getenv("DFINE_MSDA_SORT_DEBUG") ? atoi(getenv("DFINE_MSDA_SORT_DEBUG")) : 0);
   DFINE_LAUNCH_CHECK();
   return 0;
@@ -940,9 +948,11 @@ extern "C" long long dfine_msda_sorted_records(int n_calls, int B, int S, int Lq
 }
 
 extern "C" int dfine_msda_bwd_value_sorted(int value_dtype, const void* const* loc, const void* const* attn, const void* const* grad_out,
-                                           int n_calls, float* grad_value, void* entries, long long entries_cap, int B, int S, int Lq,
-                                           int nH, int c, int n_levels, const int32_t* level_hw, const int32_t* num_points, void* stream) {
+                                           int n_calls, void* grad_value, int grad_dtype, void* entries, long long entries_cap, int B, int S,
+                                           int Lq, int nH, int c, int n_levels, const int32_t* level_hw, const int32_t* num_points, void* stream) {
   if (!loc || !attn || !grad_out || !grad_value || !entries || !level_hw || !num_points) return DFINE_E_BADARG;
+  if (grad_dtype != DFINE_DT_F32 && grad_dtype != DFINE_DT_BF16) return DFINE_E_UNSUPPORTED;
+  const int ob = grad_dtype == DFINE_DT_BF16;
   if (n_calls <= 0 || B <= 0 || S <= 0 || Lq <= 0 || nH <= 0 || entries_cap <= 0) return DFINE_E_BADARG;
   if (n_calls > MSDA_MAX_CALLS) return DFINE_E_UNSUPPORTED;
   MsdaGeom g;
@@ -956,9 +966,9 @@ extern "C" int dfine_msda_bwd_value_sorted(int value_dtype, const void* const* l
   }
   hipStream_t st = (hipStream_t)stream;
   uint2* en = static_cast<uint2*>(entries);
-  if (value_dtype == DFINE_DT_BF16 && c == 32) return launch_bwd_value_sorted<bf16_t, 32>(calls, grad_value, en, entries_cap, g, B, S, Lq, nH, st);
-  if (value_dtype == DFINE_DT_BF16 && c == 16) return launch_bwd_value_sorted<bf16_t, 16>(calls, grad_value, en, entries_cap, g, B, S, Lq, nH, st);
-  if (value_dtype == DFINE_DT_F32 && c == 32) return launch_bwd_value_sorted<float, 32>(calls, grad_value, en, entries_cap, g, B, S, Lq, nH, st);
-  if (value_dtype == DFINE_DT_F32 && c == 16) return launch_bwd_value_sorted<float, 16>(calls, grad_value, en, entries_cap, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_BF16 && c == 32) return launch_bwd_value_sorted<bf16_t, 32>(calls, grad_value, ob, en, entries_cap, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_BF16 && c == 16) return launch_bwd_value_sorted<bf16_t, 16>(calls, grad_value, ob, en, entries_cap, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_F32 && c == 32) return launch_bwd_value_sorted<float, 32>(calls, grad_value, ob, en, entries_cap, g, B, S, Lq, nH, st);
+  if (value_dtype == DFINE_DT_F32 && c == 16) return launch_bwd_value_sorted<float, 16>(calls, grad_value, ob, en, entries_cap, g, B, S, Lq, nH, st);
   return DFINE_E_UNSUPPORTED;
 }

@@ -143,7 +143,7 @@ class _MSDeformAttnCore(torch.autograd.Function):
         if ctx.sink is not None and not ctx.finalize:
             sink.expect_consumer()
             return None, grad_loc, grad_attn, None, None, None, None
-        return sink.flush().to(value.dtype), grad_loc, grad_attn, None, None, None, None
+        return sink.flush(out_dtype=value.dtype).to(value.dtype), grad_loc, grad_attn, None, None, None, None
 
 
 # How d(loss)/d(value) of the deformable attention is formed (DFINE_MSDA_VALUE):
@@ -185,8 +185,9 @@ class ValueGradSink:
         self.meta = meta
         self.pending.append((loc, attn, grad_out))
 
-    def flush(self):
-        """fp32 [B, S, nH, c] gradient of every call so far (None if there was none); empties the sink."""
+    def flush(self, out_dtype=torch.float32):
+        """[B, S, nH, c] gradient of every call so far (None if there was none); empties the sink. fp32, or -- ``out_dtype``
+        bfloat16, honoured by the sorted gather only -- the fp32 sums rounded once (anything else comes back fp32)."""
         if self.buffer is not None:
             total, self.buffer = self.buffer, None
             return total
@@ -202,17 +203,18 @@ class ValueGradSink:
         if MSDA_VALUE_GRAD == "sorted" and len(self.pending) <= 8:
             n = len(self.pending)
             arr = lambda k: (ctypes.c_void_p * n)(*[t[k].data_ptr() for t in self.pending])
-            total = torch.empty(B, S, nH, c, dtype=torch.float32, device=device)
+            odt = torch.bfloat16 if out_dtype == torch.bfloat16 else torch.float32
+            total = torch.empty(B, S, nH, c, dtype=odt, device=device)
             cap = int(lib.dfine_msda_sorted_records(n, B, S, Lq, nH, P))
             entries = torch.empty(cap, 2, dtype=torch.int32, device=device)
             es = 2 if dtype == torch.bfloat16 else 4
             hits = n * B * Lq * nH * P * 4  # bound: every corner inside its map
             # bytes: points read twice (count, fill), one 8-byte record written and read per hit, a grad_out row per hit (from
             # L2), the gradient written once
-            nbytes = 2 * n * B * Lq * nH * P * 12 + hits * (16 + c * es) + total.numel() * 4
+            nbytes = 2 * n * B * Lq * nH * P * 12 + hits * (16 + c * es) + total.numel() * total.element_size()
             with _lib.timed("msda_bwd_value", nbytes):
-                rc = lib.dfine_msda_bwd_value_sorted(code, arr(0), arr(1), arr(2), n, _lib.ptr(total), _lib.ptr(entries), cap, B, S, Lq, nH, c,
-                                                     len(num_points), hw, npts, _lib.stream_ptr())
+                rc = lib.dfine_msda_bwd_value_sorted(code, arr(0), arr(1), arr(2), n, _lib.ptr(total), _lib.dtype_code(total), _lib.ptr(entries), cap,
+                                                     B, S, Lq, nH, c, len(num_points), hw, npts, _lib.stream_ptr())
             _lib.check(rc, "dfine_msda_bwd_value_sorted")
             self.pending, self.meta = [], None
             return total
@@ -278,7 +280,10 @@ class _SelectRows(torch.autograd.Function):
         idx_e, scale = ctx.saved_tensors
         B, S, D = ctx.shape
         sink = ctx.sink
-        total = sink.flush() if sink is not None else None  # every deformable-attention call's value gradient, one launch
+        # every deformable-attention call's value gradient, one launch -- in the memory's own dtype where the sink can form it
+        # so (the sorted gather sums in fp32 registers and rounds once): autograd would add this node's rows to that gradient in
+        # the memory's dtype anyway, and a bf16 map saves a conversion pass over [B, S, D]
+        total = sink.flush(out_dtype=ctx.dtype) if sink is not None else None
         if total is None:
             total = torch.zeros(B, S, D, dtype=torch.float32, device=g.device)
         total.view(B, S, D).scatter_add_(1, idx_e, (g * scale).to(total.dtype))

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 21
+#define DFINE_ABI_VERSION 22
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -654,14 +654,14 @@ int dfine_msda_bwd_value(int value_dtype, const void* const* loc /* host */, con
  * (reference src/d_fine/arch/utils.py:191-264, backward of the grid_sample gather; all decoder layers sample the same
  * memory, dfine_decoder.py:449) WITHOUT float atomics: one workgroup per (image, head[, token range]) counting-sorts that
  * (image, head)'s (call, query, point, corner) hits by token in LDS, writes 8-byte records into its own segment of `entries`
- * and then sums every token's list in registers from the grad_out rows. grad_value f32 [B, S, nH, c] is WRITTEN, every element
- * exactly once (no zero fill). `entries`: 8-byte records, entries_cap >= dfine_msda_sorted_records(n_calls, B, S, Lq, nH, P)
+ * and then sums every token's list in fp32 registers from the grad_out rows. grad_value [B, S, nH, c], f32 or bf16 (grad_dtype:
+ * the sum rounded once), is WRITTEN, every element exactly once (no zero fill). `entries`: 8-byte records, entries_cap >= dfine_msda_sorted_records(n_calls, B, S, Lq, nH, P)
  * (P = points per head over all levels), contents irrelevant on entry. The order inside a list follows the LDS atomics' arrival
  * order, so the fp32 sums are reproducible to rounding, like the scatter's.
  * ------------------------------------------------------------------------------------- */
 long long dfine_msda_sorted_records(int n_calls, int B, int S, int Lq, int nH, int P);
 int dfine_msda_bwd_value_sorted(int value_dtype, const void* const* loc /* host */, const void* const* attn /* host */,
-                                const void* const* grad_out /* host */, int n_calls, float* grad_value, void* entries,
+                                const void* const* grad_out /* host */, int n_calls, void* grad_value, int grad_dtype, void* entries,
                                 long long entries_cap, int B, int S, int Lq, int nH, int c, int n_levels, const int32_t* level_hw,
                                 const int32_t* num_points, void* stream);
 

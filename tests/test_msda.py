@@ -223,14 +223,20 @@ def test_sorted_value_gradient_matches_the_atomic_kernel(hip_lib, c, shapes, npt
     arr = lambda k: (ctypes.c_void_p * len(calls))(*[t[k].data_ptr() for t in calls])
     for _ in range(2):
         out = torch.full((B, S, nH, c), float("nan"), device="cuda")  # every element must be written
-        assert hip_lib.dfine_msda_bwd_value_sorted(1, arr(0), arr(1), arr(2), len(calls), _lib.ptr(out), _lib.ptr(entries), cap, B, S, Lq, nH, c,
+        assert hip_lib.dfine_msda_bwd_value_sorted(1, arr(0), arr(1), arr(2), len(calls), _lib.ptr(out), 0, _lib.ptr(entries), cap, B, S, Lq, nH, c,
                                                    len(npts), hw, np_, None) == 0
         torch.cuda.synchronize()
         assert torch.isfinite(out).all()
         scale = float(ref_value.abs().max())
         torch.testing.assert_close(out, ref_value, rtol=1e-4, atol=1e-5 * scale)
+    # bf16 output (what the training step asks for: the memory's dtype): the same fp32 sums, rounded once
+    out16 = torch.full((B, S, nH, c), float("nan"), device="cuda", dtype=torch.bfloat16)
+    assert hip_lib.dfine_msda_bwd_value_sorted(1, arr(0), arr(1), arr(2), len(calls), _lib.ptr(out16), 1, _lib.ptr(entries), cap, B, S, Lq, nH, c,
+                                               len(npts), hw, np_, None) == 0
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out16.float(), out, rtol=2 ** -7, atol=1e-5 * scale)  # one bf16 rounding of (nearly) the same sum
     # too small a record buffer is refused, not overrun
-    assert hip_lib.dfine_msda_bwd_value_sorted(1, arr(0), arr(1), arr(2), len(calls), _lib.ptr(out), _lib.ptr(entries), cap - 1, B, S, Lq, nH, c,
+    assert hip_lib.dfine_msda_bwd_value_sorted(1, arr(0), arr(1), arr(2), len(calls), _lib.ptr(out), 0, _lib.ptr(entries), cap - 1, B, S, Lq, nH, c,
                                                len(npts), hw, np_, None) == -1
 
 

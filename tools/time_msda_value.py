@@ -24,7 +24,7 @@ def run(locs, tag):
     def slab():
         assert lib.dfine_msda_bwd_value(1, arr(locs), arr(attn), arr(go), n, _lib.ptr(out), B, S, Lq, nH, c, 3, hw, np_, _lib.stream_ptr()) == 0
     def sorted_():
-        assert lib.dfine_msda_bwd_value_sorted(1, arr(locs), arr(attn), arr(go), n, _lib.ptr(out), _lib.ptr(entries), cap, B, S, Lq, nH, c, 3, hw, np_,
+        assert lib.dfine_msda_bwd_value_sorted(1, arr(locs), arr(attn), arr(go), n, _lib.ptr(out), 0, _lib.ptr(entries), cap, B, S, Lq, nH, c, 3, hw, np_,
                                                _lib.stream_ptr()) == 0
     def atomic():
         for i in range(n):
