@@ -353,7 +353,13 @@ class DFINETransformer(nn.Module):
             # the differentiable branch is re-run on the Q selected rows, the only ones with a gradient
             if topk_ind is None:
                 with torch.no_grad():
-                    scores = ops.row_max(self.enc_score_head(self.enc_output(memory * valid.to(memory.dtype))))
+                    # the reference ranks enc_output(memory * valid_mask) (dfine_decoder.py:885-905): a token whose anchor is
+                    # invalid contributes a ZERO row, and a zero row scores the same wherever it sits -- so the S tokens go
+                    # through unmasked and the invalid ones take the score of ONE zero row pushed through the same two modules
+                    # (row-wise ops: bit-equal), instead of a multiply over [B, S, D]
+                    scores = ops.row_max(self.enc_score_head(self.enc_output(memory)))
+                    zero_score = ops.row_max(self.enc_score_head(self.enc_output(memory.new_zeros(1, 1, hid))))
+                    scores = torch.where(valid.view(1, S), scores, zero_score.view(1, 1))
                     topk_ind = torch.topk(scores, Q, dim=-1).indices
             topk_mem = self.enc_output(ops.select_rows(memory, topk_ind, valid, sink))
             topk_logits = self.enc_score_head(topk_mem)
