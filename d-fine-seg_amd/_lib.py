@@ -51,6 +51,7 @@ SIGNATURES = {
     "dfine_adamw_ema_step": [_c_void_p] * 8 + [ctypes.POINTER(ctypes.c_longlong), _c_int, ctypes.c_longlong, _c_void_p],
     "dfine_igemm_bf16": [_c_void_p] * 7,
     "dfine_igemm_bf16_bnred": [_c_void_p] * 6,
+    "dfine_igemm_bf16_relumask": [_c_void_p] * 5 + [_c_int, _c_void_p],
     "dfine_msda_bwd_points": [_c_void_p, _c_int] + [_c_void_p] * 5 + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
     "dfine_msda_bwd_value": [_c_int] + [ctypes.POINTER(_c_void_p)] * 3 + [_c_int, _c_void_p] + [_c_int] * 6 + [_i32p, _i32p, _c_void_p],
     "dfine_msda_bwd_value_sorted": [_c_int] + [ctypes.POINTER(_c_void_p)] * 3 + [_c_int, _c_void_p, _c_int, _c_void_p, ctypes.c_longlong]
@@ -78,7 +79,7 @@ SIGNATURES = {
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int, _c_void_p, _c_int, _c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 _lib = None
 
 IGEMM_MAX_TAPS = 16

@@ -387,8 +387,9 @@ static int igemm_entry(const void* A, const void* Bw, void* C, const float* bias
   const char* fb = getenv("DFINE_IGEMM_V");  // read per call: tools/bench_igemm_cfg.py switches it at run time
   const int forced_body = fb ? atoi(fb) : 0;
   const bool use_v2 = forced_body == 2 || (forced_body != 1 && !g.gather);
-  if (br != nullptr) {  // input gradient + the producing norm's backward reductions (igemm_bnred.h)
+  if (br != nullptr) {  // input gradient + the producing norm's backward reductions (igemm_bnred.h) / a ReLU mask (red == NULL)
     if (vec != 8 || !ovec8 || g.N % 8 != 0 || stats || bias) return DFINE_E_UNSUPPORTED;
+    if (br->red == nullptr && g.gather) return DFINE_E_UNSUPPORTED;  // the mask epilogue exists in the plain-rows body only
     if (!g.gather) return igemm2_run(A, Bw, C, bias, stats, g, a_extent, ovec8, st, br);
     return ig_dispatch_bnred(A, Bw, C, g, *br, st);
   }
@@ -417,5 +418,15 @@ extern "C" int dfine_igemm_bf16_bnred(const void* A, const void* Bw, void* C, co
   br.x = (const bf16_t*)bnred->x, br.dy2 = (const bf16_t*)bnred->dy2;
   br.mean = bnred->mean, br.rstd = bnred->rstd, br.gamma = bnred->gamma, br.beta = bnred->beta, br.lab_scale = bnred->lab_scale;
   br.red = bnred->red, br.ldx = bnred->ldx, br.ld_dy2 = bnred->ld_dy2, br.act = bnred->act;
+  return igemm_entry(A, Bw, C, nullptr, nullptr, geom, &br, stream);
+}
+
+extern "C" int dfine_igemm_bf16_relumask(const void* A, const void* Bw, void* C, const dfine_igemm_geom* geom, const void* mask,
+                                         int ld_mask, void* stream) {
+  if (!mask || !geom) return DFINE_E_BADARG;
+  if (ld_mask < geom->N) return DFINE_E_BADARG;
+  if (geom->gather || ld_mask % 8 != 0 || (uintptr_t)mask % 16 != 0 || (geom->act & 0x400)) return DFINE_E_UNSUPPORTED;
+  IgBnRed br{};
+  br.x = (const bf16_t*)mask, br.ldx = ld_mask;
   return igemm_entry(A, Bw, C, nullptr, nullptr, geom, &br, stream);
 }

@@ -57,7 +57,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 //                   nothing else is written;
 //   EPI_MASK_DZ     the accumulators are turned into d(loss)/d(logit) in place (given d(loss)/d(stats)) and leave through
 //                   the ordinary store path as a bf16 [B*HW, N] matrix -- the operand of the two backward GEMMs.
-enum { EPI_PLAIN = 0, EPI_MASK_STATS = 1, EPI_MASK_DZ = 2, EPI_BNRED = 3 };  // EPI_BNRED: igemm_bnred.h
+enum { EPI_PLAIN = 0, EPI_MASK_STATS = 1, EPI_MASK_DZ = 2, EPI_BNRED = 3, EPI_RELUMASK = 4 };  // EPI_BNRED: igemm_bnred.h
+// EPI_RELUMASK: an input-gradient launch whose output is d(loss)/d(x) for x = relu(.) of the PREVIOUS Linear (the MLPs of the
+// decoder, reference dfine_decoder.py:33-46, and its FFN :233-271): the epilogue zeroes the elements where x <= 0 (x = `br.x`,
+// pitch `br.ldx`: the tensor this launch's layer consumed) -- the ReLU's backward without its own pass over [M, N]
 struct Ig2Mask {
   const float* tgt;     // [B][G][HW] fp32 ground-truth masks at the logit resolution
   const float* alpha;   // [B][G]
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((EPI == 3 && Ig2Cfg<WM, WN, FMW, FNW
     for (int i = 0; i < BMH / ORPP; ++i) {
       const int ml = o_r + i * ORPP, m = m0 + h * BMH + ml;
       if (m >= g.M || nvalid == 0) continue;
-      const uint4 v = *reinterpret_cast<const uint4*>(ct + ml * CPITCH + o_j * 8);
+      uint4 v = *reinterpret_cast<const uint4*>(ct + ml * CPITCH + o_j * 8);
       size_t orow;
       if (GATHER) {
         const int px = m % g.PW, t = m / g.PW;
@@ -426,6 +429,15 @@ __global__ __launch_bounds__(WM * WN * 64, ((EPI == 3 && Ig2Cfg<WM, WN, FMW, FNW
         orow = ((size_t)(b * g.OHf + py * g.osy + g.ooy) * g.OWf + px * g.osx + g.oox) * g.ldc;
       } else {
         orow = (size_t)m * g.ldc;
+      }
+      if (EPI == EPI_RELUMASK && nvalid == 8) {  // the consumed activation's ReLU backward: keep where x > 0
+        const uint4 xm = *reinterpret_cast<const uint4*>(br.x + (orow / g.ldc) * (size_t)br.ldx + ncol);
+        auto keep = [](uint32_t val, uint32_t x) -> uint32_t {
+          const uint32_t lo = ((x & 0x8000u) || !(x & 0x7fffu)) ? 0u : (val & 0xffffu);
+          const uint32_t hi = ((x & 0x80000000u) || !(x & 0x7fff0000u)) ? 0u : (val & 0xffff0000u);
+          return lo | hi;
+        };
+        v.x = keep(v.x, xm.x), v.y = keep(v.y, xm.y), v.z = keep(v.z, xm.z), v.w = keep(v.w, xm.w);
       }
       bf16_t* dst = C + orow + ncol;
       if (accumulate) {  // C += result: the second of two input gradients of one tensor
@@ -537,6 +549,14 @@ static int ig2_dispatch(const void* A, const void* Bw, void* C, const float* bia
   while (bn > 32 && m_tiles * ((g.N + bn - 1) / bn) < 200) bn >>= 1;
   int cfg = 2240130 + (bn / 32) * 1000;  // 128 x bn, 4 waves, K step 32, 3 stages
   if (forced) cfg = forced;
+  if (br != nullptr && br->red == nullptr) {  // ReLU-mask epilogue (EPI_RELUMASK): br carries the mask tensor only
+    if (GATHER || !ovec8 || g.N % 8 != 0 || stats != nullptr || (g.act & 0x400)) return DFINE_E_UNSUPPORTED;
+    switch (bn) {
+      case 128: return ig2_launch<2, 2, 4, 4, 32, 3, false, false, EPI_RELUMASK>(A, Bw, C, bias, stats, g, a_bytes, b_bytes, ovec8, st, Ig2Mask{}, *br);
+      case 64: return ig2_launch<2, 2, 4, 2, 32, 3, false, false, EPI_RELUMASK>(A, Bw, C, bias, stats, g, a_bytes, b_bytes, ovec8, st, Ig2Mask{}, *br);
+      default: return ig2_launch<2, 2, 4, 1, 32, 3, false, false, EPI_RELUMASK>(A, Bw, C, bias, stats, g, a_bytes, b_bytes, ovec8, st, Ig2Mask{}, *br);
+    }
+  }
   if (br != nullptr) {  // the producing norm's backward reductions in the epilogue (igemm_bnred.h): default tiles only
     if (GATHER || !ovec8 || g.N % 8 != 0 || stats != nullptr) return DFINE_E_UNSUPPORTED;
     switch (bn) {

@@ -124,7 +124,9 @@ class DecoderLayer(nn.Module):
         tgt = self.norm1(tgt, self.self_attn(tgt + pos, tgt, blocked))
         cross = self.cross_attn(tgt + pos, ref_boxes, value, spatial_shapes, sink, finalize).to(tgt.dtype)
         tgt = self.gateway(tgt, cross)
-        ffn = self.linear2(ops.linear(tgt, self.linear1.weight, self.linear1.bias, relu=True))  # bias + ReLU in the GEMM epilogue
+        # bias + ReLU in linear1's GEMM epilogue; the ReLU's backward in the epilogue of linear2's input-gradient GEMM
+        hidden = ops.linear(tgt, self.linear1.weight, self.linear1.bias, relu=True, mask_by_consumer=True)
+        ffn = ops.linear(hidden, self.linear2.weight, self.linear2.bias, relu_in=True)
         return self.norm3(tgt, ffn, clamp=65504.0)
 
 

@@ -117,8 +117,10 @@ def _check_bf16(*ts):
             raise _lib.DfineHipError(f"igemm operands must be bfloat16, got {t.dtype}")
 
 
-def linear_forward(x, w, bias=None, relu=False, out=None, name="gemm_fwd"):
-    """x [M, K] rows (pitch >= K), w [N, K] dense bf16, bias f32 [N] -> [M, N] bf16 (``out``: a pixel-row view)."""
+def linear_forward(x, w, bias=None, relu=False, out=None, name="gemm_fwd", relu_mask=None):
+    """x [M, K] rows (pitch >= K), w [N, K] dense bf16, bias f32 [N] -> [M, N] bf16 (``out``: a pixel-row view).
+    ``relu_mask`` ([M, N] bf16 rows; input-gradient launches): the result is zeroed where ``relu_mask <= 0`` in the GEMM's
+    epilogue (dfine_igemm_bf16_relumask) -- the backward of the ReLU that produced the layer's input."""
     _check_bf16(x, w)
     x, lda = as_pixel_rows(x)
     M, K = x.shape
@@ -133,6 +135,20 @@ def linear_forward(x, w, bias=None, relu=False, out=None, name="gemm_fwd"):
     if ldc is None:
         raise _lib.DfineHipError("linear_forward: output must be a pixel-row view")
     g = _geom(M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc, gather=0, act=1 if relu else 0)
+    if relu_mask is not None and bias is None and not relu:
+        ldm = pixel_pitch(relu_mask)
+        if ldm is not None and tuple(relu_mask.shape) == (M, N):
+            lib = _lib.load()
+            _lib.require_gpu(x, w, out, relu_mask)
+            with _lib.timed(name + "_rows", (M * K + N * K + 2 * M * N) * 2, f"linear M{M} N{N} K{K} +relu mask", flops=2.0 * M * N * K):
+                rc = lib.dfine_igemm_bf16_relumask(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), ctypes.byref(g), _lib.ptr(relu_mask), ldm,
+                                                   _lib.stream_ptr())
+            if rc == 0:
+                return out
+            if rc != -2:
+                _lib.check(rc, "dfine_igemm_bf16_relumask")
+        _launch(x, w, out, bias, None, g, name, f"linear M{M} N{N} K{K}")  # shapes off the 16-byte paths: GEMM, then the mask
+        return torch.ops.aten.threshold_backward(out, relu_mask, 0)
     _launch(x, w, out, bias, None, g, name, f"linear M{M} N{N} K{K}")
     return out
 

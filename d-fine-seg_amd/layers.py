@@ -263,7 +263,8 @@ class MLP(nn.Module):
     def forward(self, x):
         last = len(self.layers) - 1
         for i, layer in enumerate(self.layers):
-            x = ops.linear(x, layer.weight, layer.bias, relu=i < last)  # bias + ReLU in the GEMM epilogue
+            # bias + ReLU in the GEMM epilogue; a ReLU's backward in the epilogue of the NEXT layer's input-gradient GEMM
+            x = ops.linear(x, layer.weight, layer.bias, relu=i < last, relu_in=i > 0, mask_by_consumer=i < last)
         return x
 
 

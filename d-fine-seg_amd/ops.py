@@ -1741,7 +1741,7 @@ class _Linear(torch.autograd.Function):
     (dfine_igemm_bf16), weight/bias gradient by the split-M MFMA kernel (dfine_linear_wgrad)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, row_begin, row_end, relu):
+    def forward(ctx, x, weight, bias, row_begin, row_end, relu, relu_in=False, mask_by_consumer=False):
         from . import gemm
 
         x16 = x.to(torch.bfloat16)
@@ -1750,7 +1750,10 @@ class _Linear(torch.autograd.Function):
         w16 = bf16_of(weight)[row_begin:row_end]
         b32 = bias.detach()[row_begin:row_end].float() if bias is not None else None
         y = gemm.linear_forward(x2, w16, b32, relu)
-        ctx.save_for_backward(x2, y if relu else None)
+        ctx.save_for_backward(x2, y if (relu and not mask_by_consumer) else None)
+        # relu_in: x is the output of the previous Linear's fused ReLU and THIS layer's input-gradient GEMM applies that ReLU's
+        # backward in its epilogue; mask_by_consumer: this layer's own ReLU is handled that way by the next layer (MLP chains)
+        ctx.relu_chain = (bool(relu_in), bool(mask_by_consumer))
         ctx.params = (weight, bias, row_begin, row_end, relu, x16.shape)
         return y.reshape(*x16.shape[:-1], row_end - row_begin) if y.is_contiguous() else y.unflatten(0, x16.shape[:-1])
 
@@ -1762,8 +1765,9 @@ class _Linear(torch.autograd.Function):
         weight, bias, r0, r1, relu, x_shape = ctx.params
         lib = _lib.load()
         N, K = r1 - r0, weight.shape[1]
+        relu_in, mask_by_consumer = ctx.relu_chain
         gy16 = gy.to(torch.bfloat16).reshape(-1, N)
-        if relu:
+        if relu and not mask_by_consumer:  # (otherwise the gradient arrives masked from the next layer's input-gradient GEMM)
             gy16 = torch.ops.aten.threshold_backward(gy16, y.reshape(-1, N), 0)  # one launch instead of compare + multiply
         if not gy16.is_contiguous():
             gy16 = gy16.contiguous()
@@ -1771,7 +1775,7 @@ class _Linear(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             wt = bf16_t_of(weight)[:, r0:r1]  # [K, N] rows of pitch N_total: read in place
-            dx = gemm.linear_forward(gy16, wt, None, False, name="gemm_dgrad").view(x_shape)
+            dx = gemm.linear_forward(gy16, wt, None, False, name="gemm_dgrad", relu_mask=x2 if relu_in else None).view(x_shape)
         direct = (DIRECT_WGRAD_ACCUM and weight.grad is not None and weight.grad.dtype == torch.float32
                   and weight.grad.is_contiguous() and (bias is None or (bias.grad is not None and bias.grad.is_contiguous())))
         if direct:
@@ -1784,21 +1788,26 @@ class _Linear(torch.autograd.Function):
             prob = _lib.WgradProblem(dY=gy16.data_ptr(), X=x2.data_ptr(), dW=dw.data_ptr(), db=db.data_ptr() if db is not None else None,
                                      conv=0, M=M, N=N, K=K, ldw=K, ldy=N, ldx=K)
             if wgrad_queue.add(prob, (gy16, x2), nbytes, flops):
-                return dx, None, None, None, None, None
+                return dx, None, None, None, None, None, None, None
         with on_wgrad_stream(gy16, x2 if direct else None) if direct else _NullCtx():
             with _lib.timed("wgrad", nbytes, f"linear M{M} N{N} K{K}", flops=flops):
                 rc = lib.dfine_linear_wgrad(_lib.ptr(gy16), _lib.ptr(x2), _lib.ptr(dw), _lib.ptr(db), M, N, K, K, N, K, _lib.stream_ptr())
         _lib.check(rc, "dfine_linear_wgrad")
         if direct:
-            return dx, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None
         full_w = dw if (r0 == 0 and r1 == weight.shape[0]) else torch.zeros_like(weight, dtype=torch.float32).index_put_((torch.arange(r0, r1, device=dw.device),), dw)
         full_b = None
         if bias is not None:
             full_b = db if (r0 == 0 and r1 == bias.shape[0]) else torch.zeros_like(bias, dtype=torch.float32).index_put_((torch.arange(r0, r1, device=db.device),), db)
-        return dx, full_w.to(weight.dtype), (full_b.to(bias.dtype) if full_b is not None else None), None, None, None
+        return dx, full_w.to(weight.dtype), (full_b.to(bias.dtype) if full_b is not None else None), None, None, None, None, None
 
 
-def linear(x, weight, bias=None, row_begin=0, row_end=None, relu=False):
+# MLP chains: a hidden ReLU's backward applied by the next layer's input-gradient GEMM (dfine_igemm_bf16_relumask) instead of a
+# threshold_backward launch per layer; DFINE_RELU_EPILOGUE=0 switches back (A/B measurements)
+RELU_IN_NEXT_EPILOGUE = os.environ.get("DFINE_RELU_EPILOGUE", "1") != "0"
+
+
+def linear(x, weight, bias=None, row_begin=0, row_end=None, relu=False, relu_in=False, mask_by_consumer=False):
     """``relu?(F.linear(x, weight[row_begin:row_end], bias[row_begin:row_end]))``. On the GPU in bf16 mode (autocast, or
     bf16 input) forward, input gradient and weight/bias gradient are all HIP MFMA kernels; otherwise (fp32 parity
     runs, inference without grad on odd shapes) it is plain ``F.linear``."""
@@ -1817,7 +1826,9 @@ def linear(x, weight, bias=None, row_begin=0, row_end=None, relu=False):
         b32 = bias.detach()[row_begin:row_end].float() if bias is not None else None
         y = gemm.linear_forward(x16.reshape(-1, k), bf16_of(weight)[row_begin:row_end], b32, relu)
         return y.reshape(*x16.shape[:-1], n) if y.is_contiguous() else y.unflatten(0, x16.shape[:-1])
-    return _Linear.apply(x, weight, bias, row_begin, row_end, bool(relu))
+    if not RELU_IN_NEXT_EPILOGUE:
+        relu_in = mask_by_consumer = False
+    return _Linear.apply(x, weight, bias, row_begin, row_end, bool(relu), bool(relu_in), bool(mask_by_consumer))
 
 
 class _DenseConv(torch.autograd.Function):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 22
+#define DFINE_ABI_VERSION 23
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -531,6 +531,13 @@ typedef struct dfine_igemm_bnred {
 } dfine_igemm_bnred;
 int dfine_igemm_bf16_bnred(const void* A, const void* Bw, void* C, const dfine_igemm_geom* geom /* host */,
                            const dfine_igemm_bnred* bnred /* host */, void* stream);
+
+/* The same GEMM as the INPUT-GRADIENT launch of a Linear whose input x [M, N] (bf16, row pitch ld_mask) is the output of a ReLU
+ * fused into the previous Linear (MLP, reference src/d_fine/arch/dfine_decoder.py:33-46; decoder FFN :233-271): C = (A Bw^T)
+ * where x > 0, 0 elsewhere -- relu's backward (aten threshold_backward) in the epilogue instead of a pass over [M, N].
+ * Plain rows on the 16-byte paths only (N, ld_mask multiples of 8, aligned bases, no `C +=`); DFINE_E_UNSUPPORTED otherwise. */
+int dfine_igemm_bf16_relumask(const void* A, const void* Bw, void* C, const dfine_igemm_geom* geom /* host */, const void* mask,
+                              int ld_mask, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Transposed bf16 copies of weights for the input-gradient GEMMs: for each of n weights

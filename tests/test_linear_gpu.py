@@ -169,3 +169,49 @@ def test_dense_conv_matches_torch(hip_lib, k, stride, pad):
         torch.testing.assert_close(y.float(), yr.detach(), rtol=2e-2, atol=3e-2)
         torch.testing.assert_close(xd.grad.float(), xr.grad, rtol=2e-2, atol=3e-2)
         torch.testing.assert_close(wd.grad, wr.grad, rtol=1e-3, atol=3e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", [(256, 256, 256, 4), (4, 512, 256, 1), (256, 64, 1, 20), (256, 1024, 256, 33)])
+def test_mlp_chain_relu_backward_in_the_next_layers_epilogue(hip_lib, dims):
+    """layers.MLP (reference dfine_decoder.py:33-46): every hidden ReLU's backward is applied by the next layer's input-gradient
+    GEMM (dfine_igemm_bf16_relumask; shapes off the 16-byte paths take the GEMM + threshold_backward route) -- against the same
+    stack through torch.nn.functional in fp32 on the bf16-rounded weights: outputs 2e-2, input gradient 5e-2 relative L2 (two
+    bf16-rounded hidden activations and three bf16-rounded gradients in the chain); and
+    bit-equal to the separate-mask formulation (relu_in / mask_by_consumer off)."""
+    from dfine_seg_amd import ops
+    from dfine_seg_amd.layers import MLP
+
+    d_in, d_hidden, d_out, tail = dims
+    torch.manual_seed(d_in + d_hidden)
+    mlp = MLP(d_in, d_hidden, d_out, 3).cuda()
+    x = torch.randn(7, 300 + tail, d_in, device="cuda").bfloat16()
+    r = torch.randn(7, 300 + tail, d_out, device="cuda")
+
+    def run(fused):
+        xx = x.clone().requires_grad_()
+        for p in mlp.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            if fused:
+                y = mlp(xx)
+            else:
+                y = xx
+                for i, layer in enumerate(mlp.layers):
+                    y = ops.linear(y, layer.weight, layer.bias, relu=i < 2)
+        (y.float() * r).sum().backward()
+        return y.detach().float(), xx.grad.float(), [p.grad.float().clone() for p in mlp.parameters()]
+
+    y1, gx1, gp1 = run(True)
+    y0, gx0, gp0 = run(False)
+    assert torch.equal(y1, y0) and torch.equal(gx1, gx0)
+    for a, b in zip(gp1, gp0):  # weight gradients: float atomics, order varies
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()) + 1e-12)
+    xr = x.float().requires_grad_()
+    h = xr
+    for i, layer in enumerate(mlp.layers):
+        h = torch.nn.functional.linear(h, layer.weight.detach().bfloat16().float(), layer.bias.detach().float())
+        h = torch.relu(h) if i < 2 else h
+    (h * r).sum().backward()
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-12))
+    assert rel(y1, h.detach()) < 2e-2 and rel(gx1, xr.grad) < 5e-2
