@@ -29,6 +29,7 @@ SIGNATURES = {
     "dfine_dwconv_bwd_weight_workspace": [_c_int] * 6,
     "dfine_bn_act_fwd": [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 9 + [_c_int] * 4 + [ctypes.c_float] * 2 + [_c_int, _c_int, _c_void_p, _c_int, _c_void_p],
     "dfine_criterion_head": [_c_void_p, _c_int] + [_c_void_p] * 17 + [_c_int] * 5 + [ctypes.c_float] * 4 + [_c_void_p, _c_void_p],
+    "dfine_criterion_heads": [_c_void_p, _c_int, _c_int, _c_void_p],
     "dfine_criterion_head_scale": [_c_void_p, _c_int] + [_c_void_p] * 12 + [ctypes.c_longlong] * 3 + [_c_void_p],
     "dfine_linear_wgrad": [_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p],
     "dfine_conv_wgrad": [_c_void_p] * 3 + [_c_int] * 13 + [_c_void_p],
@@ -79,7 +80,7 @@ SIGNATURES = {
     "dfine_bn_act_bwd": [_c_void_p] * 3 + [_c_int, _c_void_p, _c_int, _c_int] + [_c_void_p] * 12 + [_c_int] * 4 + [ctypes.c_float] + [_c_int, _c_void_p],
 }
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 _lib = None
 
 IGEMM_MAX_TAPS = 16
@@ -92,6 +93,17 @@ class IGemmGeom(ctypes.Structure):
                                       "isy", "isx", "OHf", "OWf", "osy", "osx", "ooy", "oox", "act")] + [
         ("tap_dy", ctypes.c_byte * IGEMM_MAX_TAPS), ("tap_dx", ctypes.c_byte * IGEMM_MAX_TAPS),
         ("tap_w", ctypes.c_byte * IGEMM_MAX_TAPS)]
+
+
+class CriterionHeadArgs(ctypes.Structure):
+    """dfine_criterion_head_args of include/dfine_hip.h (one head of a batched dfine_criterion_heads launch)."""
+
+    _fields_ = ([(n, _c_void_p) for n in ("logits", "boxes", "corners", "ref_points", "teacher_corners", "teacher_logits", "own_assign",
+                                          "go_assign", "tgt_labels", "tgt_boxes", "Wn", "scalars", "terms", "d_logits", "d_boxes_l1",
+                                          "d_boxes_giou", "d_corners_fgl", "d_corners_ddf", "out")]
+                + [(n, _c_int) for n in ("B", "Q", "C", "G", "n_bins", "has_strides")]
+                + [(n, ctypes.c_float) for n in ("alpha", "gamma", "reg_scale", "temperature")]
+                + [("batch_strides", ctypes.c_longlong * 6)])
 
 
 class IGemmBnRed(ctypes.Structure):

@@ -341,7 +341,22 @@ class DFINECriterion(nn.Module):
             if BATCH_MASK_HEADS:
                 self._batched_mask_stats(jobs, tb, cache)
 
-        # order of the reference's loss dict: main, aux_i, pre, enc_i, dn_i, dn_final (masks), dn_pre
+        # order of the reference's loss dict: main, aux_i, pre, enc_i, dn_i, dn_final (masks), dn_pre.
+        # On the HIP path the heads are parked and computed by ONE launch when the block below ends (ops.CriterionBatch): the
+        # terms they put into ``losses`` are read only by the final stack
+        import contextlib
+
+        batch = ops.CriterionBatch() if (self.fused and dev.type == "cuda" and ops.CRITERION_BATCH) else contextlib.nullcontext()
+        with batch:
+            self._all_heads(head, mask_terms, main, aux, enc, outputs, own_pairs, dn_pairs, has_dn, with_masks,
+                            dn_assign if has_dn else None, dn_nb if has_dn else None)
+        # the reference's per-term nan_to_num (dfine_criterion.py:576-578) as ONE launch over the stacked terms
+        names = list(losses.keys())
+        clean = torch.nan_to_num(torch.stack([losses[k] for k in names]), nan=0.0)
+        return dict(zip(names, clean.unbind(0)))
+
+    @staticmethod
+    def _all_heads(head, mask_terms, main, aux, enc, outputs, own_pairs, dn_pairs, has_dn, with_masks, dn_assign, dn_nb):
         head(main, "", 0, local=True)
         mask_terms(main, own_pairs(0), "")
         for i, out in enumerate(aux):
@@ -360,10 +375,6 @@ class DFINECriterion(nn.Module):
                 mask_terms({"pred_mask_embed": outputs["dn_pred_mask_embed"]}, dn_pairs, "_dn_final")  # same tensor as in ``jobs``: id() keyed
             head(outputs["dn_pre_outputs"], "_dn_pre", None, local=True, dn=(dn_assign, dn_nb))
             mask_terms(outputs["dn_pre_outputs"], dn_pairs, "_dn_pre")
-        # the reference's per-term nan_to_num (dfine_criterion.py:576-578) as ONE launch over the stacked terms
-        names = list(losses.keys())
-        clean = torch.nan_to_num(torch.stack([losses[k] for k in names]), nan=0.0)
-        return dict(zip(names, clean.unbind(0)))
 
     # ------------------------------------------------------------------ per-head loss terms: HIP
     def _fused_heads(self, tb, go, gt_of_query, num_boxes, num_boxes_go, fdr, losses):

@@ -87,13 +87,13 @@ __device__ __forceinline__ float giou_loss_grad(const float4 pb, const Box& p, c
 constexpr int CRIT_TERM_REPLICAS = 64;  // terms: f32 [64][8], columns 0..4 used
 
 template <typename T>
-__global__ __launch_bounds__(256) void criterion_head_kernel(
+__device__ __forceinline__ void criterion_head_body(
     const T* __restrict__ logits, const float* __restrict__ boxes, const float* __restrict__ corners,
     const float* __restrict__ ref, const float* __restrict__ teacher_corners, const T* __restrict__ teacher_logits,
     const int32_t* __restrict__ own, const int32_t* __restrict__ go, const int64_t* __restrict__ tgt_labels,
     const float* __restrict__ tgt_boxes, const float* __restrict__ Wn, const float* __restrict__ scal,
     float* __restrict__ terms, T* __restrict__ d_logits, float* __restrict__ d_box_l1, float* __restrict__ d_box_giou,
-    float* __restrict__ d_corners_fgl, float* __restrict__ d_corners_ddf, CritArgs a) {
+    float* __restrict__ d_corners_fgl, float* __restrict__ d_corners_ddf, const CritArgs& a) {
   // scal: [0] 1/nb for vfl, [1] 1/nb for boxes+local, [2] ddf coefficient (matched), [3] (unmatched),
   //       [4..8] loss weights (vfl, bbox, giou, fgl, ddf), already folded into the normalisers below
   __shared__ float part[4][5];
@@ -232,6 +232,66 @@ __global__ __launch_bounds__(256) void criterion_head_kernel(
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void criterion_head_kernel(
+    const T* __restrict__ logits, const float* __restrict__ boxes, const float* __restrict__ corners,
+    const float* __restrict__ ref, const float* __restrict__ teacher_corners, const T* __restrict__ teacher_logits,
+    const int32_t* __restrict__ own, const int32_t* __restrict__ go, const int64_t* __restrict__ tgt_labels,
+    const float* __restrict__ tgt_boxes, const float* __restrict__ Wn, const float* __restrict__ scal,
+    float* __restrict__ terms, T* __restrict__ d_logits, float* __restrict__ d_box_l1, float* __restrict__ d_box_giou,
+    float* __restrict__ d_corners_fgl, float* __restrict__ d_corners_ddf, CritArgs a) {
+  criterion_head_body<T>(logits, boxes, corners, ref, teacher_corners, teacher_logits, own, go, tgt_labels, tgt_boxes, Wn, scal, terms, d_logits,
+                         d_box_l1, d_box_giou, d_corners_fgl, d_corners_ddf, a);
+}
+
+// Every head of a criterion call in ONE launch (blockIdx.y = head): a head's kernel is a few thousand one-row waves of long
+// dependent chains (softmax / log / IoU per row) that leave most of the chip idle -- 25 us per head, eleven heads one after
+// the other per step -- and the heads do not depend on each other. The table travels as a kernel argument (<= 12 heads).
+constexpr int CRIT_MAX_HEADS = 12;
+struct CritHead {
+  const void* logits;
+  const float* boxes;
+  const float* corners;
+  const float* ref;
+  const float* teacher_corners;
+  const void* teacher_logits;
+  const int32_t* own;
+  const int32_t* go;
+  const int64_t* tgt_labels;
+  const float* tgt_boxes;
+  const float* Wn;
+  const float* scal;
+  float* terms;
+  void* d_logits;
+  float* d_box_l1;
+  float* d_box_giou;
+  float* d_corners_fgl;
+  float* d_corners_ddf;
+  float* out;  // f32 [5]: the replicas' sums
+  CritArgs a;
+};
+struct CritHeads {
+  int n;
+  CritHead h[CRIT_MAX_HEADS];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void criterion_heads_kernel(const CritHeads tab) {
+  const CritHead& e = tab.h[blockIdx.y];
+  if ((int)blockIdx.x * 4 >= e.a.B * e.a.Q) return;  // a shorter head's surplus blocks (whole workgroup, before any barrier)
+  criterion_head_body<T>((const T*)e.logits, e.boxes, e.corners, e.ref, e.teacher_corners, (const T*)e.teacher_logits, e.own, e.go, e.tgt_labels,
+                         e.tgt_boxes, e.Wn, e.scal, e.terms, (T*)e.d_logits, e.d_box_l1, e.d_box_giou, e.d_corners_fgl, e.d_corners_ddf, e.a);
+}
+
+__global__ __launch_bounds__(64) void criterion_terms_reduce_kernel(const CritHeads tab) {
+  const CritHead& e = tab.h[blockIdx.x];
+  if (threadIdx.x < 5) {
+    float s = 0.f;
+    for (int r = 0; r < CRIT_TERM_REPLICAS; ++r) s += e.terms[r * 8 + threadIdx.x];
+    e.out[threadIdx.x] = s;
+  }
+}
+
 // Backward of a head's five weighted terms: the forward already holds d(term)/d(input); autograd hands five scalar
 // gradients (the five terms' d(loss)/d(term)) and the chain rule is
 //     d logits = d_logits * g_vfl     d boxes = d_l1 * g_l1 + d_giou * g_giou     d corners = d_fgl * g_fgl + d_ddf * g_ddf
@@ -291,16 +351,9 @@ extern "C" int dfine_criterion_head_scale(const void* d_logits, int logits_dtype
   return 0;
 }
 
-extern "C" int dfine_criterion_head(const void* logits, int logits_dtype, const float* boxes, const float* corners,
-                                    const float* ref_points, const float* teacher_corners, const void* teacher_logits,
-                                    const int32_t* own_assign, const int32_t* go_assign, const int64_t* tgt_labels,
-                                    const float* tgt_boxes, const float* Wn, const float* scalars, float* terms,
-                                    void* d_logits, float* d_boxes_l1, float* d_boxes_giou, float* d_corners_fgl,
-                                    float* d_corners_ddf, int B, int Q, int C, int G, int n_bins, float alpha,
-                                    float gamma, float reg_scale, float temperature, const long long* batch_strides, void* stream) {
-  if (!logits || !boxes || !own_assign || !go_assign || !tgt_labels || !tgt_boxes || !scalars || !terms || !d_logits ||
-      !d_boxes_l1 || !d_boxes_giou)
-    return DFINE_E_BADARG;
+static int make_crit_args(CritArgs* out, const float* corners, const float* ref_points, const float* teacher_corners, const void* teacher_logits,
+                          const float* Wn, const float* d_corners_fgl, const float* d_corners_ddf, int B, int Q, int C, int G, int n_bins,
+                          float alpha, float gamma, float reg_scale, float temperature, const long long* batch_strides) {
   if (B <= 0 || Q <= 0 || C <= 0 || G <= 0) return DFINE_E_BADARG;
   const int has_local = corners != nullptr;
   const int has_ddf = has_local && teacher_corners != nullptr;
@@ -316,6 +369,24 @@ extern "C" int dfine_criterion_head(const void* logits, int logits_dtype, const 
     }
     if (a.sb_boxes % 4 != 0 || (has_local && a.sb_ref % 4 != 0)) return DFINE_E_UNSUPPORTED;  // float4 loads
   }
+  *out = a;
+  return 0;
+}
+
+extern "C" int dfine_criterion_head(const void* logits, int logits_dtype, const float* boxes, const float* corners,
+                                    const float* ref_points, const float* teacher_corners, const void* teacher_logits,
+                                    const int32_t* own_assign, const int32_t* go_assign, const int64_t* tgt_labels,
+                                    const float* tgt_boxes, const float* Wn, const float* scalars, float* terms,
+                                    void* d_logits, float* d_boxes_l1, float* d_boxes_giou, float* d_corners_fgl,
+                                    float* d_corners_ddf, int B, int Q, int C, int G, int n_bins, float alpha,
+                                    float gamma, float reg_scale, float temperature, const long long* batch_strides, void* stream) {
+  if (!logits || !boxes || !own_assign || !go_assign || !tgt_labels || !tgt_boxes || !scalars || !terms || !d_logits ||
+      !d_boxes_l1 || !d_boxes_giou)
+    return DFINE_E_BADARG;
+  CritArgs a;
+  if (int rc = make_crit_args(&a, corners, ref_points, teacher_corners, teacher_logits, Wn, d_corners_fgl, d_corners_ddf, B, Q, C, G, n_bins, alpha,
+                              gamma, reg_scale, temperature, batch_strides))
+    return rc;
   const int rows = B * Q;
   dim3 grid((rows + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
@@ -329,6 +400,39 @@ extern "C" int dfine_criterion_head(const void* logits, int logits_dtype, const 
                        scalars, terms, (float*)d_logits, d_boxes_l1, d_boxes_giou, d_corners_fgl, d_corners_ddf, a);
   else
     return DFINE_E_UNSUPPORTED;
+  DFINE_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dfine_criterion_heads(const dfine_criterion_head_args* heads, int n_heads, int logits_dtype, void* stream) {
+  if (!heads || n_heads <= 0) return DFINE_E_BADARG;
+  if (logits_dtype != DFINE_DT_BF16 && logits_dtype != DFINE_DT_F32) return DFINE_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  for (int first = 0; first < n_heads; first += CRIT_MAX_HEADS) {
+    CritHeads tab;
+    tab.n = n_heads - first < CRIT_MAX_HEADS ? n_heads - first : CRIT_MAX_HEADS;
+    int max_rows = 0;
+    for (int i = 0; i < tab.n; ++i) {
+      const dfine_criterion_head_args& q = heads[first + i];
+      if (!q.logits || !q.boxes || !q.own_assign || !q.go_assign || !q.tgt_labels || !q.tgt_boxes || !q.scalars || !q.terms || !q.d_logits ||
+          !q.d_boxes_l1 || !q.d_boxes_giou || !q.out)
+        return DFINE_E_BADARG;
+      CritHead& e = tab.h[i];
+      if (int rc = make_crit_args(&e.a, q.corners, q.ref_points, q.teacher_corners, q.teacher_logits, q.Wn, q.d_corners_fgl, q.d_corners_ddf, q.B, q.Q,
+                                  q.C, q.G, q.n_bins, q.alpha, q.gamma, q.reg_scale, q.temperature, q.has_strides ? q.batch_strides : nullptr))
+        return rc;
+      e.logits = q.logits, e.boxes = q.boxes, e.corners = q.corners, e.ref = q.ref_points;
+      e.teacher_corners = e.a.has_ddf ? q.teacher_corners : nullptr, e.teacher_logits = e.a.has_ddf ? q.teacher_logits : nullptr;
+      e.own = q.own_assign, e.go = q.go_assign, e.tgt_labels = q.tgt_labels, e.tgt_boxes = q.tgt_boxes, e.Wn = q.Wn, e.scal = q.scalars;
+      e.terms = q.terms, e.d_logits = q.d_logits, e.d_box_l1 = q.d_boxes_l1, e.d_box_giou = q.d_boxes_giou;
+      e.d_corners_fgl = q.d_corners_fgl, e.d_corners_ddf = q.d_corners_ddf, e.out = q.out;
+      if (q.B * q.Q > max_rows) max_rows = q.B * q.Q;
+    }
+    const dim3 grid((max_rows + 3) / 4, tab.n), block(256);
+    if (logits_dtype == DFINE_DT_BF16) hipLaunchKernelGGL(criterion_heads_kernel<bf16_t>, grid, block, 0, st, tab);
+    else hipLaunchKernelGGL(criterion_heads_kernel<float>, grid, block, 0, st, tab);
+    hipLaunchKernelGGL(criterion_terms_reduce_kernel, dim3(tab.n), dim3(64), 0, st, tab);
+  }
   DFINE_LAUNCH_CHECK();
   return 0;
 }

@@ -924,6 +924,49 @@ def split_rows(t, n):
     return _SplitRows.apply(t, int(n))
 
 
+criterion_batch = None  # an open CriterionBatch, or None: every criterion_head call launches by itself
+CRITERION_BATCH = os.environ.get("DFINE_CRITERION_BATCH", "1") != "0"  # (A/B measurements)
+
+
+class CriterionBatch:
+    """Collects the heads of one criterion call so that ONE dfine_criterion_heads launch computes them all (their kernels are
+    independent and each leaves most of the chip idle). ``with CriterionBatch():`` around the ``criterion_head`` calls; the
+    terms they return are filled when the block ends -- nothing may read them before."""
+
+    def __init__(self):
+        self.heads, self.keep, self.dtype, self.nbytes = [], [], None, 0
+
+    def add(self, args, dtype, tensors, nbytes):
+        self.heads.append(args)
+        self.keep.append(tensors)
+        self.dtype = dtype
+        self.nbytes += nbytes
+
+    def __enter__(self):
+        global criterion_batch
+        if criterion_batch is not None:
+            raise _lib.DfineHipError("CriterionBatch: already open")
+        criterion_batch = self
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        global criterion_batch
+        criterion_batch = None
+        if exc_type is None and self.heads:
+            self.launch()
+        self.heads, self.keep = [], []
+        return False
+
+    def launch(self):
+        lib = _lib.load()
+        n = len(self.heads)
+        arr = (_lib.CriterionHeadArgs * n)(*self.heads)
+        with _lib.timed("criterion_head", self.nbytes, f"{n} heads"):
+            rc = lib.dfine_criterion_heads(ctypes.cast(arr, ctypes.c_void_p), n, _lib.DT_BF16 if self.dtype == torch.bfloat16 else _lib.DT_F32,
+                                           _lib.stream_ptr())
+        _lib.check(rc, "dfine_criterion_heads")
+
+
 class _CriterionHead(torch.autograd.Function):
     """Weighted loss terms of one head + their gradients; see include/dfine_hip.h (dfine_criterion_head)."""
 
@@ -966,6 +1009,26 @@ class _CriterionHead(torch.autograd.Function):
         d_giou = torch.empty_like(d_l1)
         d_fgl = torch.empty(corners.shape, dtype=torch.float32, device=dev) if has_local else None
         d_ddf = torch.empty(corners.shape, dtype=torch.float32, device=dev) if has_ddf else None
+        batch = criterion_batch
+        if batch is not None and (not batch.heads or batch.dtype == logits.dtype):
+            # a CriterionBatch is open (DFINECriterion.forward): park the head; ONE launch computes every head when it closes,
+            # before anybody reads the terms returned here
+            out = torch.empty(5, dtype=torch.float32, device=dev)
+            a = _lib.CriterionHeadArgs(
+                logits=logits.data_ptr(), boxes=boxes.data_ptr(), corners=corners.data_ptr() if has_local else None,
+                ref_points=ref_points.data_ptr() if has_local else None, teacher_corners=teacher_corners.data_ptr() if has_ddf else None,
+                teacher_logits=teacher_logits.data_ptr() if has_ddf else None, own_assign=own.data_ptr(), go_assign=go.data_ptr(),
+                tgt_labels=tgt_labels.data_ptr(), tgt_boxes=tgt_boxes.data_ptr(), Wn=Wn.data_ptr() if Wn is not None else None,
+                scalars=scalars.data_ptr(), terms=terms.data_ptr(), d_logits=d_logits.data_ptr(), d_boxes_l1=d_l1.data_ptr(),
+                d_boxes_giou=d_giou.data_ptr(), d_corners_fgl=d_fgl.data_ptr() if has_local else None,
+                d_corners_ddf=d_ddf.data_ptr() if has_ddf else None, out=out.data_ptr(), B=B, Q=Q, C=C, G=G, n_bins=n_bins, has_strides=1,
+                alpha=alpha, gamma=gamma, reg_scale=reg_scale, temperature=temperature, batch_strides=(ctypes.c_longlong * 6)(*strides))
+            batch.add(a, logits.dtype, (logits, boxes, corners, ref_points, teacher_corners, teacher_logits, own, go, tgt_labels, tgt_boxes, Wn,
+                                        scalars, terms, d_logits, d_l1, d_giou, d_fgl, d_ddf, out),
+                      logits.numel() * logits.element_size() * 2 + (corners.numel() * 16 if has_local else 0))
+            ctx.save_for_backward(d_logits, d_l1, d_giou, d_fgl, d_ddf)
+            ctx.mark_non_differentiable()
+            return tuple(out.unbind(0))
         with _lib.timed("criterion_head", logits.numel() * logits.element_size() * 2 + (corners.numel() * 16 if has_local else 0)):
             rc = lib.dfine_criterion_head(
                 _lib.ptr(logits), _lib.dtype_code(logits), _lib.ptr(boxes), _lib.ptr(corners), _lib.ptr(ref_points),

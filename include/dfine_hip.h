@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DFINE_ABI_VERSION 23
+#define DFINE_ABI_VERSION 24
 
 /* element types of `value`/`out` tensors */
 #define DFINE_DT_F32 0
@@ -269,6 +269,35 @@ int dfine_criterion_head(const void* logits, int logits_dtype, const float* boxe
                          void* d_logits, float* d_boxes_l1, float* d_boxes_giou, float* d_corners_fgl,
                          float* d_corners_ddf, int B, int Q, int C, int G, int n_bins, float alpha, float gamma,
                          float reg_scale, float temperature, const long long* batch_strides, void* stream);
+
+/* Every head of one criterion call in ONE launch: the arguments of dfine_criterion_head per head (a HOST array of n_heads
+ * structs), all heads with logits of one dtype; `terms` as there (f32 [64][8], zeroed by the caller) and additionally
+ * out f32 [5] = the replicas' sums (written by a second tiny launch). has_strides = 0: dense inputs. */
+typedef struct dfine_criterion_head_args {
+  const void* logits;
+  const float* boxes;
+  const float* corners;
+  const float* ref_points;
+  const float* teacher_corners;
+  const void* teacher_logits;
+  const int32_t* own_assign;
+  const int32_t* go_assign;
+  const int64_t* tgt_labels;
+  const float* tgt_boxes;
+  const float* Wn;
+  const float* scalars;
+  float* terms;
+  void* d_logits;
+  float* d_boxes_l1;
+  float* d_boxes_giou;
+  float* d_corners_fgl;
+  float* d_corners_ddf;
+  float* out;
+  int B, Q, C, G, n_bins, has_strides;
+  float alpha, gamma, reg_scale, temperature;
+  long long batch_strides[6];
+} dfine_criterion_head_args;
+int dfine_criterion_heads(const dfine_criterion_head_args* heads /* host */, int n_heads, int logits_dtype, void* stream);
 
 /* Backward of dfine_criterion_head's five terms (autograd of the weighted sums in DFINECriterion.forward,
  * src/d_fine/dfine_criterion.py:560-580): given the five terms' upstream scalar gradients g_* (device f32 [1] each; NULL = 0),

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 
 def test_abi_version(hip_lib):
-    assert hip_lib.dfine_abi_version() == 23
+    assert hip_lib.dfine_abi_version() == 24
 
 
 def test_bad_arguments_are_rejected_without_launch(hip_lib):
