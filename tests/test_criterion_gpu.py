@@ -129,3 +129,37 @@ def test_head_reads_slices_of_a_wider_decoder_output_in_place(hip_lib):
             outs.append((torch.stack(terms).detach(), lg.grad, bx.grad, cr.grad))
         for a, b in zip(*outs):
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_one_launch_for_all_heads_equals_one_launch_per_head(hip_lib, dtype):
+    """ops.CriterionBatch / dfine_criterion_heads: the heads of a criterion call computed by ONE launch (blockIdx.y = head, heads
+    of 300 and of 200 queries, with and without corners / teacher) against one launch per head -- the same kernel body: every loss
+    term and every gradient bit for bit (the five sums of a head are float atomics into 64 replicas in both: compared to 1e-6)."""
+    from dfine_seg_amd import ops
+    from dfine_seg_amd.configs import CriterionSpec
+    from dfine_seg_amd.criterion import DFINECriterion
+
+    counts = [3, 0, 7, 1]
+    B, Q, C, L = len(counts), 300, 80, 3
+    Nd = 2 * 7 * (100 // 7)
+    results = {}
+    old = ops.CRITERION_BATCH
+    try:
+        for batched in (False, True):
+            ops.CRITERION_BATCH = batched
+            out, leaves = _outputs(B, Q, Nd, C, counts, L, seed=9, dtype=dtype)
+            losses = DFINECriterion(CriterionSpec(), num_classes=C, fused=True)(out)
+            torch.stack(list(losses.values())).sum().backward()
+            results[batched] = ({k: float(v) for k, v in losses.items()}, [t.grad.clone() if t.grad is not None else None for t in leaves])
+    finally:
+        ops.CRITERION_BATCH = old
+    one, all_ = results[False], results[True]
+    assert list(one[0].keys()) == list(all_[0].keys())
+    for k in one[0]:
+        assert abs(one[0][k] - all_[0][k]) <= 1e-6 * abs(one[0][k]) + 1e-9, (k, one[0][k], all_[0][k])
+    for i, (ga, gb) in enumerate(zip(one[1], all_[1])):
+        assert (ga is None) == (gb is None), i
+        if ga is not None:
+            assert torch.equal(ga, gb), i
