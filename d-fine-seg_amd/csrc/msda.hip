@@ -139,6 +139,11 @@ __global__ __launch_bounds__(256) void msda_bwd_points_kernel(const T* __restric
   const float* ap = attn + (size_t)spair * g.P;
   float go[VEC];
   VecTraits<T>::unpack(*reinterpret_cast<const Vec16*>(grad_out + (size_t)spair * C + sub * VEC), go);
+  // the block's results go through LDS and leave as contiguous runs (its pairs' grad_attn / grad_loc rows are adjacent in
+  // memory): a pair's first lane storing 4 + 8 bytes per point made 24 scattered stores per pair
+  constexpr int PPB = 256 / LPP;  // pairs per workgroup
+  __shared__ float res_a[PPB * DFINE_MAX_POINTS], res_l[PPB * DFINE_MAX_POINTS * 2];
+  const int pl = threadIdx.x / LPP;
 
   for (int l = 0; l < g.n_levels; ++l) {
     const int H = g.H[l], W = g.W[l], start = g.start[l];
@@ -164,12 +169,18 @@ __global__ __launch_bounds__(256) void msda_bwd_points_kernel(const T* __restric
         s_y += go[i] * ((a10 - a00) * (1.0f - k.fx) + (a11 - a01) * k.fx);
       }
       s_v = group_sum<LPP>(s_v), s_x = group_sum<LPP>(s_x), s_y = group_sum<LPP>(s_y);
-      if (live && sub == 0) {
-        grad_attn[(size_t)pair * g.P + p] = s_v;
-        *reinterpret_cast<float2*>(grad_loc + ((size_t)pair * g.P + p) * 2) = make_float2(s_x * a * (float)W, s_y * a * (float)H);
+      if (sub == 0) {
+        res_a[pl * g.P + p] = s_v;
+        res_l[(pl * g.P + p) * 2] = s_x * a * (float)W;
+        res_l[(pl * g.P + p) * 2 + 1] = s_y * a * (float)H;
       }
     }
   }
+  __syncthreads();
+  const long long pair0 = (long long)blockIdx.x * PPB;
+  const long long n_live = min((long long)PPB, (long long)n_pairs - pair0) * g.P;  // floats of grad_attn this block owns
+  for (int i = threadIdx.x; i < n_live; i += 256) grad_attn[pair0 * g.P + i] = res_a[i];
+  for (int i = threadIdx.x; i < 2 * n_live; i += 256) grad_loc[pair0 * g.P * 2 + i] = res_l[i];
 }
 
 // ------------------------------------------------------------------------------------------
